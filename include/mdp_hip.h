@@ -1,0 +1,460 @@
+/*
+ * mdp_hip.h -- C ABI of libmdp_hip.so: the MI355X (gfx950) implementation of Isaac Lab's
+ * per-step vectorised MDP compute (actuators, sensors, manager terms, math, ray casting).
+ *
+ * Conventions:
+ *   - every pointer is a DEVICE pointer borrowed for the duration of the call (never retained,
+ *     never freed) unless the function is documented as a host-side builder;
+ *   - tensors are fp32 row-major with the row stride ("ld", in elements) passed explicitly, masks
+ *     are uint8 (torch.bool storage), ids are int32 unless noted (torch int64 buffers that the
+ *     reference owns -- episode_length_buf, command_counter -- are read as int64);
+ *   - every launch is asynchronous on the `stream` argument (a hipStream_t passed as void*);
+ *     nothing synchronises, nothing allocates after the create calls;
+ *   - return value: 0 = ok, <0 = error class (MDP_ERR_*); mdp_last_error() gives the message.
+ *     The Python shim raises the matching exception type (ValueError/RuntimeError).
+ *
+ * Each entry point cites the reference interface it replaces as `LAB/...:line`
+ * (LAB = source/isaaclab/isaaclab, TASKS = source/isaaclab_tasks/isaaclab_tasks).
+ */
+#ifndef MDP_HIP_H
+#define MDP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDP_OK 0
+#define MDP_ERR_INVALID (-1)   /* bad argument / shape  -> ValueError   */
+#define MDP_ERR_RUNTIME (-2)   /* HIP runtime failure   -> RuntimeError */
+#define MDP_ERR_UNSUPPORTED (-3)
+
+int mdp_version(void);
+const char* mdp_last_error(void);
+/* number of visible devices / name of device 0 (host only, used by smoke tests) */
+int mdp_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Actuators  (LAB/actuators/actuator_pd.py, actuator_net.py)
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    MDP_ACT_IMPLICIT = 0, /* ImplicitActuator.compute   actuator_pd.py:62-87   */
+    MDP_ACT_IDEAL_PD = 1, /* IdealPDActuator.compute    actuator_pd.py:131-145 */
+    MDP_ACT_DC_MOTOR = 2  /* DCMotor.compute/_clip_effort actuator_pd.py:211-233 */
+};
+
+/* One actuator group, one physics sub-step.  All matrices are (N, J) with row stride ld_*.
+ * q_des/qd_des/tau_ff may be NULL (treated as zeros, which is what Articulation feeds when a
+ * target was never set).  computed/applied are the group's `computed_effort` / `applied_effort`.
+ * saturation_effort is only read for MDP_ACT_DC_MOTOR (may be +inf, actuator_pd.py:195-198). */
+int mdp_actuator_pd_compute(int kind, int num_envs, int num_joints,
+                            const float* q_des, int ld_q_des,
+                            const float* qd_des, int ld_qd_des,
+                            const float* tau_ff, int ld_tau_ff,
+                            const float* joint_pos, int ld_pos,
+                            const float* joint_vel, int ld_vel,
+                            const float* stiffness, const float* damping,
+                            const float* effort_limit, const float* velocity_limit,
+                            float saturation_effort,
+                            float* computed_effort, float* applied_effort,
+                            void* stream);
+
+/* CircularBuffer / DelayBuffer (LAB/utils/buffers/circular_buffer.py:107-166,
+ * delay_buffer.py:159-177).  buffer is (max_len, N, D); num_pushes int64 (N); pointer is the
+ * *new* head slot (host-tracked python int, circular_buffer.py:126).  append back-fills every
+ * slot of rows whose num_pushes == 0 (circular_buffer.py:130-133) without a host sync, then
+ * increments num_pushes.  If out != NULL it also performs the delayed read
+ * buffer[(pointer - min(lag, pushes-1)) mod max_len, env]  (delay_buffer.py:176). */
+int mdp_circular_buffer_append(float* buffer, int64_t* num_pushes, int max_len, int num_envs, int dim,
+                               int pointer, const float* data, int ld_data,
+                               const int32_t* time_lags, float* out, void* stream);
+/* buffer property: oldest -> newest, output (N, max_len, D)  (circular_buffer.py:78-86) */
+int mdp_circular_buffer_read(const float* buffer, int max_len, int num_envs, int dim, int pointer,
+                             float* out, void* stream);
+/* reset rows flagged in env_mask (NULL = all): num_pushes = 0, buffer rows = 0 (circular_buffer.py:92-105) */
+int mdp_circular_buffer_reset(float* buffer, int64_t* num_pushes, int max_len, int num_envs, int dim,
+                              const uint8_t* env_mask, void* stream);
+
+/* LinearInterpolation.compute (LAB/utils/interpolation/linear_interpolation.py:54-85) followed,
+ * when efforts != NULL, by RemotizedPDActuator's clamp (actuator_pd.py:357-362):
+ * efforts = clamp(efforts, -f(q), +f(q)) in place.  fq (optional) receives f(q). */
+int mdp_linear_interp(const float* x, const float* y, int num_samples,
+                      const float* q, int64_t count, float* fq, float* efforts, void* stream);
+
+/* ActuatorNet weights.  A network is an (optional) LSTM stack followed by an MLP, packed on the
+ * host into MFMA A-fragment order by mdp_net_pack (host pointers in, host blob out) and uploaded
+ * by the caller.  Activation ids: 0 none, 1 elu, 2 relu, 3 tanh, 4 softsign, 5 sigmoid.  */
+typedef struct {
+    int32_t lstm_layers;   /* 0 for ActuatorNetMLP */
+    int32_t lstm_hidden;   /* multiple of 4, <= 64 */
+    int32_t lstm_input;    /* 2 for the SEA net (actuator_net.py:56) */
+    int32_t mlp_layers;    /* >= 1 (decoder / MLP) */
+    int32_t mlp_dims[9];   /* dims[0] = input width, dims[i+1] = output width of layer i; last must be 1 */
+    int32_t mlp_act[8];    /* activation after layer i (last one normally 0) */
+} mdp_net_desc_t;
+
+/* size in floats of the packed blob for `desc` */
+int64_t mdp_net_packed_size(const mdp_net_desc_t* desc);
+/* weights: host array of pointers in PyTorch state_dict order:
+ * for each LSTM layer l: weight_ih_l (4H,in), weight_hh_l (4H,H), bias_ih_l (4H), bias_hh_l (4H);
+ * then for each MLP layer: weight (out,in), bias (out).  All row-major fp32 host memory. */
+int mdp_net_pack(const mdp_net_desc_t* desc, const float* const* weights, float* packed_out);
+
+/* ActuatorNetLSTM.compute (actuator_net.py:76-99): rows = N*J; x = [q_des - q, qd];
+ * (h, c) are (L, rows, H) updated in place; torque -> computed (N*J); DC-motor clip -> applied. */
+int mdp_actuator_lstm_compute(const mdp_net_desc_t* desc, const float* packed_weights,
+                              int num_envs, int num_joints,
+                              const float* q_des, int ld_q_des,
+                              const float* joint_pos, int ld_pos,
+                              const float* joint_vel, int ld_vel,
+                              float* hidden_state, float* cell_state,
+                              const float* effort_limit, const float* velocity_limit, float saturation_effort,
+                              float* computed_effort, float* applied_effort, void* stream);
+/* ActuatorNetLSTM.reset (actuator_net.py:70-74): zero (h, c)[:, env] for rows flagged in env_mask (NULL = all). */
+int mdp_actuator_lstm_reset(int layers, int hidden, int num_envs, int num_joints,
+                            float* hidden_state, float* cell_state, const uint8_t* env_mask, void* stream);
+
+/* ActuatorNetMLP.compute (actuator_net.py:147-188).  Histories are (N, Hlen, J); instead of
+ * rolling the whole history every sub-step (actuator_net.py:152-156) the kernel shifts in place.
+ * input_idx (device int32, n_idx taps), input_order 0 = pos_vel, 1 = vel_pos. */
+int mdp_actuator_mlp_compute(const mdp_net_desc_t* desc, const float* packed_weights,
+                             int num_envs, int num_joints, int history_len,
+                             const float* q_des, int ld_q_des,
+                             const float* joint_pos, int ld_pos,
+                             const float* joint_vel, int ld_vel,
+                             float* pos_err_history, float* vel_history,
+                             const int32_t* input_idx, int n_idx, int input_order,
+                             float pos_scale, float vel_scale, float torque_scale,
+                             const float* effort_limit, const float* velocity_limit, float saturation_effort,
+                             float* computed_effort, float* applied_effort, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scene update (state container + sensors)
+ * ------------------------------------------------------------------------------------------ */
+
+/* ArticulationData.update -> joint_acc finite difference + previous-velocity side effect
+ * (LAB/assets/articulation/articulation_data.py:77-82,446-455).  inv_dt = 1/elapsed. */
+int mdp_joint_acc_update(int num_envs, int num_joints, const float* joint_vel, int ld_vel,
+                         float* prev_joint_vel, float* joint_acc, float elapsed, void* stream);
+
+/* root_state_w / body_state_w assembly (articulation_data.py:264-279,329-346): pose (count,7) in the
+ * physics engine's xyzw convention + velocity (count,6) -> state (count,13) with wxyz quaternions. */
+int mdp_state_pack(int64_t count, const float* pose_xyzw, const float* velocity, float* state_out, void* stream);
+
+/* Derived root quantities (articulation_data.py:412-425,503-518): any output may be NULL.
+ * root_state is (N,13) [pos, quat wxyz, lin_vel, ang_vel]; gravity_dir is the unit gravity vector. */
+int mdp_root_derive(int num_envs, const float* root_state, int ld_state,
+                    float gx, float gy, float gz,
+                    float* root_lin_vel_b, float* root_ang_vel_b, float* projected_gravity_b,
+                    float* heading_w, void* stream);
+
+/* root_link_state_w COM->link velocity correction (articulation_data.py:288-302), works for
+ * bodies too: count = N or N*B poses (ld 13 in / out), com_pos_b (count,3). */
+int mdp_link_state_from_com(int64_t count, const float* state_in, const float* com_pos_b, float* state_out,
+                            void* stream);
+
+/* SensorBase.update + ContactSensor._update_buffers_impl
+ * (LAB/sensors/sensor_base.py:197-205,284-293; contact_sensor/contact_sensor.py:314-373).
+ * timestamp += dt; outdated |= (timestamp - last_update + 1e-6 >= update_period); then for
+ * outdated envs: net_forces_w <- forces, history shift, air/contact-time state machine,
+ * last_update = timestamp, outdated = 0.  history may be NULL when history_length == 0
+ * (then net_forces_w itself is the (N,1,B,3) history view).  timers may be NULL
+ * (track_air_time False). */
+int mdp_contact_sensor_update(int num_envs, int num_bodies, int history_len,
+                              const float* net_contact_forces, /* (N,B,3) from the physics view */
+                              float* net_forces_w, float* net_forces_w_history,
+                              float* last_air_time, float* current_air_time,
+                              float* last_contact_time, float* current_contact_time,
+                              float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
+                              float dt, float update_period, float force_threshold, int eager,
+                              void* stream);
+/* ContactSensor.reset / SensorBase.reset for rows flagged in env_mask (contact_sensor.py:136-155). */
+int mdp_contact_sensor_reset(int num_envs, int num_bodies, int history_len,
+                             float* net_forces_w, float* net_forces_w_history,
+                             float* last_air_time, float* current_air_time,
+                             float* last_contact_time, float* current_contact_time,
+                             float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
+                             const uint8_t* env_mask, void* stream);
+/* plain SensorBase.update for lazily evaluated sensors (RayCaster): timestamps + outdated flag only. */
+int mdp_sensor_tick(int num_envs, float* timestamp, const float* timestamp_last_update, uint8_t* is_outdated,
+                    float dt, float update_period, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Ray casting (LAB/utils/warp/ops.py:24-145, kernels.py:13-75; LAB/sensors/ray_caster/ray_caster.py:220-260)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mdp_mesh mdp_mesh_t;
+
+/* convert_to_warp_mesh (ops.py:130-145): HOST points (V,3) fp32 and indices (M,3) int32; builds the
+ * acceleration structures (uniform xy cell grid + LBVH) on the host and uploads them to `device`.
+ * accel: 0 = auto, 1 = grid, 2 = bvh. */
+int mdp_mesh_create(const float* points, int num_points, const int32_t* indices, int num_tris,
+                    int device, int accel, mdp_mesh_t** out);
+int mdp_mesh_destroy(mdp_mesh_t* mesh);
+/* introspection used by tests / DESIGN.md numbers */
+int mdp_mesh_info(const mdp_mesh_t* mesh, int64_t* num_tris, int64_t* num_cells, int64_t* num_cell_refs,
+                  int64_t* num_bvh_nodes, int64_t* device_bytes, int* accel);
+
+/* raycast_mesh (ops.py:24-127): closest hit of each ray; outputs pre-filled by the kernel with
+ * +inf / -1 on a miss (ops.py:70,78,85,92).  dist/normal/face_id may be NULL.  accel: 0 = mesh default. */
+int mdp_raycast(const mdp_mesh_t* mesh, int64_t num_rays,
+                const float* ray_starts, const float* ray_dirs, float max_dist,
+                float* ray_hits, float* ray_dist, float* ray_normal, int32_t* ray_face_id,
+                int accel, void* stream);
+
+/* RayCaster._update_buffers_impl fused with the lazy-update bookkeeping
+ * (ray_caster.py:220-260, sensor_base.py:284-293): for every env whose is_outdated flag is set
+ * (or all when is_outdated == NULL): pos_w = root_pos + drift, quat_w = root quat, rays from the
+ * (R,3) local pattern (yaw-only or full attach), cast, write ray_hits_w (N,R,3); then
+ * last_update = timestamp, outdated = 0.  root_pose: (N, >=7) [pos, quat wxyz] with row stride ld. */
+int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int num_rays,
+                         const float* root_pose, int ld_pose, const float* drift,
+                         const float* ray_starts_local, const float* ray_dirs_local,
+                         int attach_yaw_only, float max_dist,
+                         float* pos_w, float* quat_w, float* ray_hits_w,
+                         const float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Manager term programs (LAB/managers/{observation,reward,termination}_manager.py,
+ * LAB/envs/mdp/{observations,rewards,terminations}.py, TASKS/.../velocity/mdp/ *.py)
+ * ------------------------------------------------------------------------------------------ */
+
+/* One lowered term.  Pointer slots and scalar slots are interpreted per opcode (see the tables in
+ * isaaclab_amd/csrc/programs.hip and isaaclab_amd/_terms.py).  The struct is plain data and is
+ * copied to the device by mdp_program_create. */
+typedef struct {
+    int32_t op;
+    int32_t out_offset;   /* obs: first output column; reward/termination: term slot */
+    int32_t dim;          /* obs: number of columns */
+    int32_t n_idx;        /* -1 = all (0..count-1), else number of entries at idx_offset in the index pool */
+    int32_t idx_offset;
+    int32_t n_idx2;
+    int32_t idx2_offset;
+    int32_t i0, i1, i2, i3;
+    int64_t l0;
+    float f0, f1, f2, f3, f4, f5;
+    const void* p0;
+    const void* p1;
+    const void* p2;
+    const void* p3;
+    const void* p4;
+    const void* p5;
+    /* observation post-processing (observation_manager.py:313-318) */
+    int32_t noise_kind;   /* 0 none, 1 uniform, 2 gaussian, 3 constant */
+    int32_t noise_op;     /* 0 add, 1 scale, 2 abs  (noise_model.py:35-42) */
+    float n0, n1;         /* uniform: n_min, n_max; gaussian: mean, std; constant: bias */
+    const float* noise_u; /* optional injected random numbers (N, dim) used instead of the generator */
+    int32_t has_clip;
+    float clip_lo, clip_hi;
+    int32_t has_scale;    /* 1 scalar `scale`, 2 per-column scale_vec */
+    float scale;
+    const float* scale_vec;
+    /* reward: weight (reward_manager.py:148) ; termination: time_out flag in i3 */
+    float weight;
+} mdp_term_t;
+
+/* Ray-caster binding for a fused height-scan observation term (op MDP_OBS_HEIGHT_SCAN_CAST): the
+ * term's p4 holds a HOST pointer to this struct at mdp_program_create time; the builder copies it
+ * (and the mesh view) to the device.  Field meaning as in mdp_raycaster_update. */
+typedef struct {
+    const mdp_mesh_t* mesh;
+    int32_t num_rays;
+    int32_t attach_yaw_only;
+    float max_dist;
+    int32_t ld_pose;
+    const float* root_pose;
+    const float* drift;
+    const float* ray_starts_local;
+    const float* ray_dirs_local;
+    float* pos_w;
+    float* quat_w;
+    float* ray_hits_w;
+    const float* timestamp;
+    float* timestamp_last_update;
+    uint8_t* is_outdated;
+} mdp_raycaster_desc_t;
+
+typedef struct mdp_program mdp_program_t;
+
+enum { MDP_PROG_OBS = 0, MDP_PROG_REWARD = 1, MDP_PROG_TERMINATION = 2 };
+
+/* host-side builder: copies `terms` (host) and the index pool (host int32) to `device`. */
+int mdp_program_create(int kind, int device, int num_envs, const mdp_term_t* terms, int num_terms,
+                       const int32_t* index_pool, int index_pool_len, uint64_t seed, mdp_program_t** out);
+int mdp_program_destroy(mdp_program_t* prog);
+
+/* ObservationManager.compute_group (observation_manager.py:260-335): obs is (N, ld_obs) with the
+ * group's terms concatenated at their out_offset.  Terms with a fused height scan also update the
+ * ray caster buffers exactly like mdp_raycaster_update. */
+int mdp_obs_compute(mdp_program_t* prog, float* obs, int ld_obs, void* stream);
+
+/* RewardManager.compute (reward_manager.py:128-157): reward_buf (N); episode_sums (T,N) row per
+ * term; step_reward (N,T).  Terms with weight == 0 are skipped exactly like the reference. */
+int mdp_reward_compute(mdp_program_t* prog, float dt, float* reward_buf, float* episode_sums,
+                       float* step_reward, void* stream);
+
+/* TerminationManager.compute (termination_manager.py:151-174): term_dones (T,N) uint8,
+ * truncated/terminated (N) uint8, dones (N) = truncated | terminated (optional). */
+int mdp_termination_compute(mdp_program_t* prog, uint8_t* term_dones, uint8_t* truncated,
+                            uint8_t* terminated, uint8_t* dones, void* stream);
+
+/* Stand-alone evaluation of ONE lowered term (the stock `func(env, **params)` term functions call
+ * this when used outside a manager; LAB/managers/manager_base.py:250-267 contract).  `term` is a
+ * HOST pointer and travels as a kernel argument; index_pool is a DEVICE int32 array (or NULL).
+ * out: obs -> float (N, ld_out); reward -> float (N); termination -> uint8 (N). */
+int mdp_term_eval(int kind, const mdp_term_t* term, const int32_t* index_pool, int num_envs, void* out,
+                  int ld_out, uint64_t seed, uint64_t epoch, void* stream);
+
+/* generic post-processing for the unfused path: in place on data (N, dim) (observation_manager.py:313-318),
+ * described by the post-processing fields of `term` (a HOST pointer); seed/offset key the generator. */
+int mdp_obs_postprocess(const mdp_term_t* term, int num_envs, float* data, int ld, uint64_t seed,
+                        uint64_t offset, void* stream);
+
+/* Class modifiers (LAB/utils/modifiers/modifier.py:67-259).  count = number of data elements.
+ * DigitalFilter.__call__ (:170-191): x_hist (count, nb) / y_hist (count, na) are rolled by one in place,
+ * y = x_hist . B - y_hist . A;  A, B device vectors.  Integrator.__call__ (:245-259): integral +=
+ * (data + y_prev)/2 * dt; y_prev = data; out = integral.  Reset zeroes rows of flagged envs
+ * (per_env elements each). */
+int mdp_modifier_digital_filter(int64_t count, const float* data, float* x_hist, int nb, float* y_hist, int na,
+                                const float* B, const float* A, float* out, void* stream);
+int mdp_modifier_integrator(int64_t count, const float* data, float* integral, float* y_prev, float dt,
+                            float* out, void* stream);
+int mdp_rows_zero(float* buf, int num_envs, int64_t per_env, const uint8_t* env_mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * UniformVelocityCommand (LAB/envs/mdp/commands/velocity_command.py:111-160,
+ * LAB/managers/command_manager.py:151-187)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    float resampling_time_lo, resampling_time_hi;
+    float lin_vel_x_lo, lin_vel_x_hi, lin_vel_y_lo, lin_vel_y_hi, ang_vel_z_lo, ang_vel_z_hi;
+    float heading_lo, heading_hi;
+    float rel_standing_envs, rel_heading_envs;
+    float heading_control_stiffness;
+    int32_t heading_command;
+    float max_command_step;   /* resampling_time_range[1] / step_dt (velocity_command.py:113-114) */
+} mdp_velocity_command_cfg_t;
+
+/* CommandTerm.compute: metrics, time_left -= dt, resample where <= 0 (command_counter += 1), update.
+ * rng_state: device uint64[2] {seed, epoch}; epoch is advanced by the kernel (graph-replay safe).
+ * injected_u: optional (N,7) uniforms [time, vx, vy, wz, heading, is_heading, is_standing] used instead
+ * of the generator (parity tests).  force_mask: optional (N) uint8 -> resample exactly those envs
+ * regardless of time_left (CommandTerm.reset path, command_manager.py:120-149; metrics are then
+ * zeroed for them and command_counter set to 1). */
+int mdp_velocity_command_compute(const mdp_velocity_command_cfg_t* cfg, int num_envs,
+                                 const float* root_state, int ld_state,
+                                 float* vel_command_b, float* heading_target,
+                                 uint8_t* is_heading_env, uint8_t* is_standing_env,
+                                 float* time_left, int64_t* command_counter,
+                                 float* metric_error_vel_xy, float* metric_error_vel_yaw,
+                                 float dt, uint64_t* rng_state, const float* injected_u,
+                                 const uint8_t* force_mask, void* stream);
+
+/* JointAction.process_actions (LAB/envs/mdp/actions/joint_actions.py:130-139) +
+ * ActionManager.process_action bookkeeping (LAB/managers/action_manager.py:331-332):
+ * prev_action = action; action = in; processed = raw*scale + offset [clip]. */
+int mdp_joint_action_process(int num_envs, int action_dim, const float* actions_in, int ld_in,
+                             float* action, float* prev_action, float* processed,
+                             const float* scale_vec, float scale, const float* offset /* (N,A) or NULL */,
+                             const float* clip /* (N,A,2) or NULL */, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * isaaclab.utils.math kernels (LAB/utils/math.py) -- op ids in enum, generic batched launcher.
+ * a/b/c are input rows with widths given per op; out width given per op (see mathops.hip table).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    MDP_MATH_QUAT_MUL = 0,            /* math.py:463-499 */
+    MDP_MATH_QUAT_CONJUGATE = 1,      /* :223-235 */
+    MDP_MATH_QUAT_INV = 2,            /* :238-248 */
+    MDP_MATH_QUAT_UNIQUE = 3,         /* :447-460 */
+    MDP_MATH_QUAT_ROTATE = 4,         /* :582-602 */
+    MDP_MATH_QUAT_ROTATE_INVERSE = 5, /* :605-625 */
+    MDP_MATH_QUAT_APPLY = 6,          /* :545-564 */
+    MDP_MATH_QUAT_APPLY_YAW = 7,      /* :567-579 */
+    MDP_MATH_YAW_QUAT = 8,            /* :521-542 */
+    MDP_MATH_QUAT_FROM_EULER_XYZ = 9, /* :251-278  a=(n,3) roll,pitch,yaw */
+    MDP_MATH_EULER_XYZ_FROM_QUAT = 10,/* :413-444  out=(n,3) */
+    MDP_MATH_AXIS_ANGLE_FROM_QUAT = 11,/* :645-674 (f0 = eps) */
+    MDP_MATH_QUAT_ERROR_MAGNITUDE = 12,/* :677-689 */
+    MDP_MATH_QUAT_BOX_MINUS = 13,     /* :502-518 */
+    MDP_MATH_QUAT_FROM_ANGLE_AXIS = 14,/* :628-642 a=(n,1) angle, b=(n,3) axis */
+    MDP_MATH_MATRIX_FROM_QUAT = 15,   /* :143-174 out=(n,9) */
+    MDP_MATH_QUAT_FROM_MATRIX = 16,   /* :294-349 a=(n,9) */
+    MDP_MATH_WRAP_TO_PI = 17,         /* :95-117  width 1 */
+    MDP_MATH_NORMALIZE = 18,          /* :81-92   width = i0, f0 = eps */
+    MDP_MATH_SCALE_TRANSFORM = 19,    /* :22-40   width 1, a=x b=lower c=upper */
+    MDP_MATH_UNSCALE_TRANSFORM = 20,  /* :43-61 */
+    MDP_MATH_SATURATE = 21,           /* :64-78 */
+    MDP_MATH_COMBINE_FRAME = 22,      /* :749-781 a=t01 b=q01 c=t12 d=q12 out=(n,7) */
+    MDP_MATH_SUBTRACT_FRAME = 23,     /* :785-816 out=(n,7) */
+    MDP_MATH_COMPUTE_POSE_ERROR = 24, /* :820-869 out=(n,6) axis-angle or (n,7) quat (i0=1) */
+    MDP_MATH_APPLY_DELTA_POSE = 25,   /* :872-910 a=pos b=quat c=delta(6) out=(n,7), f0 = eps */
+    MDP_MATH_SKEW = 26,               /* :692-720 out=(n,9) */
+    MDP_MATH_COPYSIGN = 27,           /* :120-135 f0 = mag */
+    MDP_MATH_NUM_OPS = 28
+};
+/* Broadcast: a row stride of 0 repeats row 0 (e.g. a (dims,) lower/upper bound). */
+int mdp_math_op(int op, int64_t n,
+                const float* a, int lda, const float* b, int ldb,
+                const float* c, int ldc, const float* d, int ldd,
+                float* out, int ldo, int i0, float f0, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Shadow-hand in-hand manipulation, direct workflow
+ * (TASKS/direct/inhand_manipulation/inhand_manipulation_env.py:97-117,179-199,262-433)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t num_envs, num_dofs, num_actuated, num_fingertips, num_bodies;
+    float act_moving_average, vel_obs_scale;
+    float dist_reward_scale, rot_reward_scale, rot_eps, action_penalty_scale, success_tolerance,
+          reach_goal_bonus, fall_dist, fall_penalty, av_factor;
+    int32_t max_consecutive_success;
+    int64_t max_episode_length;
+} mdp_inhand_cfg_t;
+
+/* _apply_action (inhand_manipulation_env.py:97-117): scale -> moving average -> saturate, in place
+ * on cur_targets / prev_targets (N, num_dofs) for the actuated columns (device int32 indices). */
+int mdp_inhand_apply_action(const mdp_inhand_cfg_t* cfg, const float* actions, const int32_t* actuated_idx,
+                            const float* lower, const float* upper, float* cur_targets, float* prev_targets,
+                            void* stream);
+/* _get_dones (:179-199): out_of_reach, time_out (uint8); episode_length_buf (int64) reset on success
+ * when max_consecutive_success > 0. */
+int mdp_inhand_dones(const mdp_inhand_cfg_t* cfg, const float* object_root_state /* (N,13) */,
+                     const float* env_origins, const float* in_hand_pos, const float* goal_rot,
+                     const float* successes, int64_t* episode_length_buf,
+                     uint8_t* out_of_reach, uint8_t* time_out, void* stream);
+/* compute_rewards (:377-433).  reset_buf / reset_goal_buf uint8 in; goal_resets uint8 out (may alias
+ * reset_goal_buf); successes in/out; partial sums (2 doubles: num_resets, sum(successes*resets)) are
+ * accumulated into `partials` (device double[2], zeroed by the kernel's first phase) and
+ * consecutive_successes (1) is updated by mdp_inhand_finish_rewards after an optional cross-rank
+ * all-reduce of `partials`. */
+int mdp_inhand_rewards(const mdp_inhand_cfg_t* cfg, const float* object_root_state, const float* env_origins,
+                       const float* in_hand_pos, const float* goal_rot, const float* actions,
+                       const uint8_t* reset_buf, const uint8_t* reset_goal_buf, float* successes,
+                       float* reward, uint8_t* goal_resets, double* partials, void* stream);
+int mdp_inhand_finish_rewards(const mdp_inhand_cfg_t* cfg, const double* partials,
+                              float* consecutive_successes, void* stream);
+/* compute_full_observations (:298-322): obs (N, 2*dofs + 13 + 11 + 13*tips + actions). */
+int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joint_pos, const float* joint_vel,
+                        const float* lower, const float* upper,
+                        const float* object_root_state, const float* env_origins,
+                        const float* in_hand_pos, const float* goal_rot,
+                        const float* body_state_w /* (N,B,13) */, const int32_t* finger_bodies,
+                        const float* actions, int action_dim, float* obs, int ld_obs, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Statistics for the cross-GPU reductions: per-rank partials in fp64.
+ * ------------------------------------------------------------------------------------------ */
+/* obs-normaliser partials of x (N,D): out[0]=N, out[1..D]=sum x, out[1+D..2D]=sum (x-mean_r)^2
+ * (Chan-mergeable; my_code/models/my_running_standard_scaler.py:57-80). */
+int mdp_stats_moments(const float* x, int num_envs, int dim, int ld, double* out, void* stream);
+/* masked sum/count of per-env scalars (episode statistics at reset; reward_manager.py:115-121):
+ * out[2*k] = sum_{mask} values[k][env], out[2*k+1] = count, for k rows of a (K,N) matrix. */
+int mdp_stats_masked_sums(const float* values, int rows, int num_envs, const uint8_t* mask, double* out,
+                          void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDP_HIP_H */

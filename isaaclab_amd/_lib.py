@@ -1,0 +1,226 @@
+"""ctypes binding of ``libmdp_hip.so`` (the C ABI declared in ``include/mdp_hip.h``).
+
+The product path never falls back to torch/CPU arithmetic: if the shared library is missing the
+import fails loudly, and every wrapper raises if a tensor does not live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libmdp_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(hipcc --offload-arch=gfx950).  isaaclab_amd has no CPU / torch fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+MDP_OK = 0
+MDP_ERR_INVALID = -1
+MDP_ERR_RUNTIME = -2
+MDP_ERR_UNSUPPORTED = -3
+
+lib.mdp_last_error.restype = C.c_char_p
+lib.mdp_version.restype = C.c_int
+lib.mdp_net_packed_size.restype = C.c_int64
+
+
+class MdpTerm(C.Structure):
+    """Mirror of ``mdp_term_t``."""
+
+    _fields_ = [
+        ("op", C.c_int32), ("out_offset", C.c_int32), ("dim", C.c_int32),
+        ("n_idx", C.c_int32), ("idx_offset", C.c_int32), ("n_idx2", C.c_int32), ("idx2_offset", C.c_int32),
+        ("i0", C.c_int32), ("i1", C.c_int32), ("i2", C.c_int32), ("i3", C.c_int32),
+        ("l0", C.c_int64),
+        ("f0", C.c_float), ("f1", C.c_float), ("f2", C.c_float), ("f3", C.c_float), ("f4", C.c_float), ("f5", C.c_float),
+        ("p0", C.c_void_p), ("p1", C.c_void_p), ("p2", C.c_void_p), ("p3", C.c_void_p), ("p4", C.c_void_p), ("p5", C.c_void_p),
+        ("noise_kind", C.c_int32), ("noise_op", C.c_int32), ("n0", C.c_float), ("n1", C.c_float),
+        ("noise_u", C.c_void_p),
+        ("has_clip", C.c_int32), ("clip_lo", C.c_float), ("clip_hi", C.c_float),
+        ("has_scale", C.c_int32), ("scale", C.c_float), ("scale_vec", C.c_void_p),
+        ("weight", C.c_float),
+    ]
+
+
+class MdpRaycasterDesc(C.Structure):
+    _fields_ = [
+        ("mesh", C.c_void_p), ("num_rays", C.c_int32), ("attach_yaw_only", C.c_int32), ("max_dist", C.c_float),
+        ("ld_pose", C.c_int32), ("root_pose", C.c_void_p), ("drift", C.c_void_p),
+        ("ray_starts_local", C.c_void_p), ("ray_dirs_local", C.c_void_p),
+        ("pos_w", C.c_void_p), ("quat_w", C.c_void_p), ("ray_hits_w", C.c_void_p),
+        ("timestamp", C.c_void_p), ("timestamp_last_update", C.c_void_p), ("is_outdated", C.c_void_p),
+    ]
+
+
+class MdpVelocityCommandCfg(C.Structure):
+    _fields_ = [
+        ("resampling_time_lo", C.c_float), ("resampling_time_hi", C.c_float),
+        ("lin_vel_x_lo", C.c_float), ("lin_vel_x_hi", C.c_float),
+        ("lin_vel_y_lo", C.c_float), ("lin_vel_y_hi", C.c_float),
+        ("ang_vel_z_lo", C.c_float), ("ang_vel_z_hi", C.c_float),
+        ("heading_lo", C.c_float), ("heading_hi", C.c_float),
+        ("rel_standing_envs", C.c_float), ("rel_heading_envs", C.c_float),
+        ("heading_control_stiffness", C.c_float), ("heading_command", C.c_int32),
+        ("max_command_step", C.c_float),
+    ]
+
+
+class MdpNetDesc(C.Structure):
+    _fields_ = [
+        ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),
+        ("mlp_layers", C.c_int32), ("mlp_dims", C.c_int32 * 9), ("mlp_act", C.c_int32 * 8),
+    ]
+
+
+class MdpInhandCfg(C.Structure):
+    _fields_ = [
+        ("num_envs", C.c_int32), ("num_dofs", C.c_int32), ("num_actuated", C.c_int32),
+        ("num_fingertips", C.c_int32), ("num_bodies", C.c_int32),
+        ("act_moving_average", C.c_float), ("vel_obs_scale", C.c_float),
+        ("dist_reward_scale", C.c_float), ("rot_reward_scale", C.c_float), ("rot_eps", C.c_float),
+        ("action_penalty_scale", C.c_float), ("success_tolerance", C.c_float), ("reach_goal_bonus", C.c_float),
+        ("fall_dist", C.c_float), ("fall_penalty", C.c_float), ("av_factor", C.c_float),
+        ("max_consecutive_success", C.c_int32), ("max_episode_length", C.c_int64),
+    ]
+
+
+def _parse_defines(path: str, prefix: str) -> dict[str, int]:
+    out = {}
+    with open(path) as f:
+        for line in f:
+            m = re.match(r"#define\s+(" + prefix + r"\w+)\s+(-?\d+)", line)
+            if m:
+                out[m.group(1)] = int(m.group(2))
+    return out
+
+
+OPS = _parse_defines(os.path.join(_HERE, "csrc", "term_ops.h"), "MDP_")
+
+
+def _parse_enum(path: str, prefix: str) -> dict[str, int]:
+    out = {}
+    with open(path) as f:
+        for m in re.finditer(r"(" + prefix + r"\w+)\s*=\s*(\d+)", f.read()):
+            out[m.group(1)] = int(m.group(2))
+    return out
+
+
+_HDR = os.path.join(os.path.dirname(_HERE), "include", "mdp_hip.h")
+MATH_OPS = _parse_enum(_HDR, "MDP_MATH_")
+ACT_KINDS = _parse_enum(_HDR, "MDP_ACT_")
+PROG_OBS, PROG_REWARD, PROG_TERMINATION = 0, 1, 2
+
+
+def exported_symbols() -> list[str]:
+    """Every function name declared in include/mdp_hip.h (used by the ABI test)."""
+    names = []
+    with open(_HDR) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for m in re.finditer(r"\b(mdp_\w+)\s*\(", text):
+        names.append(m.group(1))
+    return sorted(set(names))
+
+
+_CTYPE = {
+    "int": C.c_int, "int32_t": C.c_int32, "int64_t": C.c_int64, "uint64_t": C.c_uint64,
+    "float": C.c_float, "double": C.c_double, "unsigned": C.c_uint,
+}
+
+
+def _bind_all():
+    """Set argtypes/restype of every prototype in include/mdp_hip.h (so python floats/ints convert)."""
+    with open(_HDR) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for m in re.finditer(r"\b(int64_t|int|const char\s*\*)\s+(mdp_\w+)\s*\(([^)]*)\)\s*;", text, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        fn = getattr(lib, name)  # AttributeError here == symbol missing from the .so
+        argtypes = []
+        for a in args.split(","):
+            a = " ".join(a.split())
+            if not a or a == "void":
+                continue
+            if "*" in a:
+                argtypes.append(C.c_void_p)
+            else:
+                ty = a.rsplit(" ", 1)[0].replace("const", "").strip()
+                argtypes.append(_CTYPE[ty])
+        fn.argtypes = argtypes
+        fn.restype = C.c_int64 if ret == "int64_t" else (C.c_char_p if "char" in ret else C.c_int)
+
+
+_bind_all()
+
+
+def last_error() -> str:
+    return (lib.mdp_last_error() or b"").decode()
+
+
+def check(rc: int):
+    if rc == MDP_OK:
+        return
+    msg = last_error()
+    if rc == MDP_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == MDP_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise RuntimeError(msg)
+
+
+def require_gpu(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor, got {type(t)}")
+    if t.device.type != "cuda":
+        raise RuntimeError(
+            f"{name} lives on '{t.device}': isaaclab_amd only computes on a HIP device (MI355X); "
+            "there is no CPU fallback."
+        )
+    return t
+
+
+def ptr(t: torch.Tensor | None):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    require_gpu(t)
+    return t.data_ptr()
+
+
+def f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    require_gpu(t, name)
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t
+
+
+def rows(t: torch.Tensor, name: str = "tensor") -> tuple[torch.Tensor, int]:
+    """Return (tensor, row stride) for a 2-D fp32 tensor whose last dim is dense; copies otherwise."""
+    t = f32(t, name)
+    if t.dim() != 2:
+        raise ValueError(f"{name} must be 2-D, got shape {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        t = t.contiguous()  # broadcast / expanded rows
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return t, int(ld)
+
+
+def stream(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def device_index(device) -> int:
+    d = torch.device(device)
+    if d.type != "cuda":
+        raise RuntimeError(f"isaaclab_amd needs a HIP device, got '{device}'")
+    return d.index if d.index is not None else torch.cuda.current_device()

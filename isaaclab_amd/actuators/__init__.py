@@ -1,0 +1,6 @@
+"""Actuator models (mirror of ``isaaclab.actuators``), HIP-backed."""
+from .actuator_base import ActuatorBase
+from .actuator_cfg import (ActuatorBaseCfg, ActuatorNetLSTMCfg, ActuatorNetMLPCfg, DCMotorCfg, DelayedPDActuatorCfg,
+                           IdealPDActuatorCfg, ImplicitActuatorCfg, RemotizedPDActuatorCfg)
+from .actuator_net import ActuatorNetLSTM, ActuatorNetMLP
+from .actuator_pd import DCMotor, DelayedPDActuator, IdealPDActuator, ImplicitActuator, RemotizedPDActuator

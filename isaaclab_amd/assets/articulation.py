@@ -1,0 +1,206 @@
+"""``Articulation`` (``LAB/assets/articulation/articulation.py``) reduced to what the hot path needs:
+name lookup, joint targets, actuator groups and ``_apply_actuator_model`` (:1399-1436)."""
+from __future__ import annotations
+
+from collections.abc import Sequence
+from dataclasses import MISSING
+
+import torch
+
+from ..actuators import ActuatorBase, ImplicitActuator
+from ..utils import string as string_utils
+from ..utils.configclass import configclass
+from ..utils.types import ArticulationActions
+from .articulation_data import ArticulationData
+
+
+@configclass
+class ArticulationCfg:
+    """Subset of ``LAB/assets/articulation/articulation_cfg.py`` consumed by the MDP path."""
+
+    joint_names: list = MISSING
+    body_names: list = MISSING
+    default_joint_pos: dict = {".*": 0.0}
+    default_joint_vel: dict = {".*": 0.0}
+    soft_joint_pos_limit_factor: float = 1.0
+    joint_pos_limits: tuple | dict = (-3.14, 3.14)   # synthetic stand-in for the USD joint limits
+    joint_vel_limits: float = 100.0
+    joint_effort_limits: float = 1000.0
+    actuators: dict = MISSING
+
+
+class Articulation:
+    def __init__(self, cfg: ArticulationCfg, root_physx_view, device: str):
+        self.cfg = cfg
+        self.device = device
+        self.root_physx_view = root_physx_view
+        self._joint_names = list(cfg.joint_names)
+        self._body_names = list(cfg.body_names)
+        self.num_instances = root_physx_view.count
+        self._data = ArticulationData(root_physx_view, device, len(self._body_names), self._body_names, self._joint_names)
+        self._ALL_INDICES = torch.arange(self.num_instances, dtype=torch.long, device=device)
+        n, j = self.num_instances, self.num_joints
+        self._joint_pos_target_sim = torch.zeros((n, j), device=device)
+        self._joint_vel_target_sim = torch.zeros((n, j), device=device)
+        self._joint_effort_target_sim = torch.zeros((n, j), device=device)
+        self._process_cfg()
+        self._process_actuators_cfg()
+
+    # -- properties -----------------------------------------------------------------------------------
+    @property
+    def data(self) -> ArticulationData: return self._data
+    @property
+    def num_joints(self) -> int: return len(self._joint_names)
+    @property
+    def num_bodies(self) -> int: return len(self._body_names)
+    @property
+    def num_fixed_tendons(self) -> int: return 0
+    @property
+    def joint_names(self) -> list[str]: return self._joint_names
+    @property
+    def body_names(self) -> list[str]: return self._body_names
+    @property
+    def fixed_tendon_names(self) -> list[str]: return []
+
+    def find_bodies(self, name_keys, preserve_order: bool = False):
+        return string_utils.resolve_matching_names(name_keys, self.body_names, preserve_order)
+
+    def find_joints(self, name_keys, joint_subset: list[str] | None = None, preserve_order: bool = False):
+        if joint_subset is None:
+            joint_subset = self.joint_names
+        return string_utils.resolve_matching_names(name_keys, joint_subset, preserve_order)
+
+    def find_fixed_tendons(self, name_keys, tendon_subsets=None, preserve_order: bool = False):
+        return string_utils.resolve_matching_names(name_keys, [], preserve_order)
+
+    # -- operations -----------------------------------------------------------------------------------
+    def reset(self, env_ids: Sequence[int] | None = None):
+        if env_ids is None:
+            env_ids = slice(None)
+        for actuator in self.actuators.values():
+            actuator.reset(env_ids)
+
+    def write_data_to_sim(self):
+        """articulation.py:172-199 (the physics-side setters are out of scope)."""
+        self._apply_actuator_model()
+
+    def update(self, dt: float):
+        self._data.update(dt)
+
+    def _set_target(self, buf: torch.Tensor, target: torch.Tensor, joint_ids, env_ids):
+        """articulation.py:807-880"""
+        if env_ids is None and (joint_ids is None or joint_ids == slice(None)):
+            if target.data_ptr() != buf.data_ptr():
+                buf.copy_(target)
+            return
+        if env_ids is None:
+            env_ids = slice(None)
+        if joint_ids is None:
+            joint_ids = slice(None)
+        if env_ids != slice(None) and joint_ids != slice(None):
+            env_ids = env_ids[:, None]
+        buf[env_ids, joint_ids] = target
+
+    def set_joint_position_target(self, target, joint_ids=None, env_ids=None):
+        self._set_target(self._data.joint_pos_target, target, joint_ids, env_ids)
+
+    def set_joint_velocity_target(self, target, joint_ids=None, env_ids=None):
+        self._set_target(self._data.joint_vel_target, target, joint_ids, env_ids)
+
+    def set_joint_effort_target(self, target, joint_ids=None, env_ids=None):
+        self._set_target(self._data.joint_effort_target, target, joint_ids, env_ids)
+
+    # -- internals ------------------------------------------------------------------------------------
+    def _process_cfg(self):
+        n, j = self.num_instances, self.num_joints
+        d = self._data
+        idx, _, vals = string_utils.resolve_matching_names_values(self.cfg.default_joint_pos, self.joint_names)
+        d.default_joint_pos[:, idx] = torch.tensor(vals, dtype=torch.float32, device=self.device)
+        idx, _, vals = string_utils.resolve_matching_names_values(self.cfg.default_joint_vel, self.joint_names)
+        d.default_joint_vel[:, idx] = torch.tensor(vals, dtype=torch.float32, device=self.device)
+        lim = self.cfg.joint_pos_limits
+        if isinstance(lim, dict):
+            idx, _, vals = string_utils.resolve_matching_names_values(lim, self.joint_names)
+            d.joint_limits[:, idx] = torch.tensor(vals, dtype=torch.float32, device=self.device)
+        else:
+            d.joint_limits[..., 0] = float(lim[0])
+            d.joint_limits[..., 1] = float(lim[1])
+        d.default_joint_limits.copy_(d.joint_limits)
+        d.joint_velocity_limits[:] = float(self.cfg.joint_vel_limits)
+        d.joint_effort_limits[:] = float(self.cfg.joint_effort_limits)
+        # soft limits = mean +- 0.5 * range * factor (articulation.py:1231-1237); init-time host math
+        mean = (d.joint_limits[..., 0] + d.joint_limits[..., 1]) / 2
+        rng = d.joint_limits[..., 1] - d.joint_limits[..., 0]
+        f = self.cfg.soft_joint_pos_limit_factor
+        d.soft_joint_pos_limits[..., 0] = mean - 0.5 * rng * f
+        d.soft_joint_pos_limits[..., 1] = mean + 0.5 * rng * f
+        d.joint_pos_target.copy_(d.default_joint_pos)
+
+    def _process_actuators_cfg(self):
+        """articulation.py:1289-1368"""
+        self.actuators: dict[str, ActuatorBase] = dict()
+        self._has_implicit_actuators = False
+        d = self._data
+        for actuator_name, actuator_cfg in self.cfg.actuators.items():
+            joint_ids, joint_names = self.find_joints(actuator_cfg.joint_names_expr)
+            if len(joint_names) == 0:
+                raise ValueError(
+                    f"No joints found for actuator group: {actuator_name} with joint name expression:"
+                    f" {actuator_cfg.joint_names_expr}."
+                )
+            actuator = actuator_cfg.class_type(
+                cfg=actuator_cfg, joint_names=joint_names,
+                joint_ids=(slice(None) if len(joint_names) == self.num_joints
+                           else torch.tensor(joint_ids, device=self.device)),
+                num_envs=self.num_instances, device=self.device,
+                stiffness=d.default_joint_stiffness[:, joint_ids], damping=d.default_joint_damping[:, joint_ids],
+                armature=d.default_joint_armature[:, joint_ids], friction=d.default_joint_friction[:, joint_ids],
+                effort_limit=d.joint_effort_limits.clone()[:, joint_ids],
+                velocity_limit=d.joint_velocity_limits.clone()[:, joint_ids],
+            )
+            self.actuators[actuator_name] = actuator
+            if isinstance(actuator, ImplicitActuator):
+                self._has_implicit_actuators = True
+            d.default_joint_stiffness[:, actuator.joint_indices] = actuator.stiffness
+            d.default_joint_damping[:, actuator.joint_indices] = actuator.damping
+        # single group over all joints: bind the data buffers to the actuator's outputs (no scatter copies)
+        if len(self.actuators) == 1:
+            act = next(iter(self.actuators.values()))
+            if act.joint_indices == slice(None):
+                d.computed_torque = act.computed_effort
+                d.applied_torque = act.applied_effort
+                d.soft_joint_vel_limits = act.velocity_limit
+                self._single_full_group = True
+                return
+        self._single_full_group = False
+
+    def _apply_actuator_model(self):
+        """articulation.py:1399-1436"""
+        d = self._data
+        for actuator in self.actuators.values():
+            ji = actuator.joint_indices
+            control_action = ArticulationActions(
+                joint_positions=d.joint_pos_target[:, ji], joint_velocities=d.joint_vel_target[:, ji],
+                joint_efforts=d.joint_effort_target[:, ji], joint_indices=ji,
+            )
+            control_action = actuator.compute(control_action, joint_pos=d.joint_pos[:, ji], joint_vel=d.joint_vel[:, ji])
+            if self._single_full_group:
+                # outputs already live in the data buffers; targets handed to physics are aliases
+                if control_action.joint_efforts is not None:
+                    self._joint_effort_target_sim = control_action.joint_efforts
+                if control_action.joint_positions is not None:
+                    self._joint_pos_target_sim = control_action.joint_positions
+                if control_action.joint_velocities is not None:
+                    self._joint_vel_target_sim = control_action.joint_velocities
+                continue
+            if control_action.joint_positions is not None:
+                self._joint_pos_target_sim[:, ji] = control_action.joint_positions
+            if control_action.joint_velocities is not None:
+                self._joint_vel_target_sim[:, ji] = control_action.joint_velocities
+            if control_action.joint_efforts is not None:
+                self._joint_effort_target_sim[:, ji] = control_action.joint_efforts
+            d.computed_torque[:, ji] = actuator.computed_effort
+            d.applied_torque[:, ji] = actuator.applied_effort
+            d.soft_joint_vel_limits[:, ji] = actuator.velocity_limit
+            if hasattr(actuator, "gear_ratio"):
+                d.gear_ratio[:, ji] = actuator.gear_ratio

@@ -1,0 +1,467 @@
+// ActuatorNetLSTM / ActuatorNetMLP on the matrix cores (v_mfma_f32_16x16x4_f32: exact-f32 MFMA).
+// Reference: LAB/actuators/actuator_net.py:30-188.
+//
+// Mapping (one wave = 16 actuator rows at a time, rows = N*J):
+//   D tile (16x16) = W (16 outputs x 4 k) * X (4 k x 16 rows); lane l -> column (row of the batch)
+//   l & 15, quad gq = l >> 4.  The weight rows are permuted on the host (mdp_net_pack) so that
+//     * LSTM tile t, D row gq*4 + r  = gate r (i,f,g,o) of hidden unit u = gq*(H/4) + t
+//       -> all four gates of a unit land in ONE lane: the cell update needs no cross-lane traffic;
+//     * the K order of the next product follows the D layout of the previous one
+//       (k-slot gq of k-step (t, r) = value held in register r of tile t by quad gq)
+//       -> layer outputs feed the next MFMA as the B operand straight from registers.
+//   Weights sit in LDS as ready-made A fragments (64 floats, one per lane, conflict-free ds_read_b32).
+// HBM traffic per row and sub-step: inputs 12 B, (h, c) 2*2*L*H*4 B, outputs 8 B -> HBM-bound
+// (SURVEY.md section 8d); the MFMA pipe is there to keep the VALU free for the gate transcendentals.
+#include "mdp_device.hpp"
+#include "mdp_host.hpp"
+
+#include <vector>
+
+using namespace mdp;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int MAX_MLP_LAYERS = 4;
+constexpr int MLP_NT = 2;  // tiles per MLP layer -> widths <= 32
+
+struct NetLayout {
+    // offsets in floats into the packed blob
+    int lstm_w[4];     // per layer: fragments [(kstep * TPL + t) * 64]
+    int lstm_b[4];     // per layer: [(t * 4 + r) * 64]
+    int lstm_ksteps_in[4];
+    int mlp_w[MAX_MLP_LAYERS];  // [((tin * 4 + r) * MLP_NT + tout) * 64] (first layer after an LSTM: [(s * MLP_NT + tout) * 64])
+    int mlp_b[MAX_MLP_LAYERS];  // [(tout * 4 + r) * 64]
+    int mlp_ksteps[MAX_MLP_LAYERS];
+    int total;
+};
+
+int tiles_for(int width) { return (width + 15) / 16; }
+
+int make_layout(const mdp_net_desc_t& d, NetLayout& L) {
+    int off = 0;
+    int H = d.lstm_hidden, TPL = H / 4;
+    for (int l = 0; l < d.lstm_layers; ++l) {
+        int ks_in = (l == 0) ? (d.lstm_input + 3) / 4 : TPL;
+        L.lstm_ksteps_in[l] = ks_in;
+        L.lstm_w[l] = off;
+        off += (ks_in + TPL) * TPL * 64;
+        L.lstm_b[l] = off;
+        off += TPL * 4 * 64;
+    }
+    for (int l = 0; l < d.mlp_layers; ++l) {
+        int ks;
+        if (l == 0) ks = d.lstm_layers > 0 ? TPL : (d.mlp_dims[0] + 3) / 4;
+        else ks = tiles_for(d.mlp_dims[l]) * 4;
+        L.mlp_ksteps[l] = ks;
+        L.mlp_w[l] = off;
+        off += ks * MLP_NT * 64;
+        L.mlp_b[l] = off;
+        off += MLP_NT * 4 * 64;
+    }
+    L.total = off;
+    return off;
+}
+
+int validate(const mdp_net_desc_t* d) {
+    MDP_REQUIRE(d, "null net desc");
+    MDP_REQUIRE(d->lstm_layers >= 0 && d->lstm_layers <= 4, "lstm_layers must be in [0,4]");
+    if (d->lstm_layers > 0) {
+        MDP_REQUIRE(d->lstm_hidden == 8 || d->lstm_hidden == 16 || d->lstm_hidden == 32,
+                    "lstm hidden size %d unsupported (8, 16, 32)", d->lstm_hidden);
+        MDP_REQUIRE(d->lstm_input >= 1 && d->lstm_input <= 4, "lstm input size %d unsupported (<= 4)", d->lstm_input);
+    }
+    MDP_REQUIRE(d->mlp_layers >= 1 && d->mlp_layers <= MAX_MLP_LAYERS, "mlp_layers must be in [1,%d]", MAX_MLP_LAYERS);
+    for (int l = 0; l <= d->mlp_layers; ++l)
+        MDP_REQUIRE(d->mlp_dims[l] >= 1 && d->mlp_dims[l] <= 16 * MLP_NT, "mlp width %d unsupported (<= %d)",
+                    d->mlp_dims[l], 16 * MLP_NT);
+    MDP_REQUIRE(d->mlp_dims[d->mlp_layers] == 1, "network output width must be 1");
+    if (d->lstm_layers > 0) MDP_REQUIRE(d->mlp_dims[0] == d->lstm_hidden, "decoder input must equal lstm hidden");
+    for (int l = 0; l < d->mlp_layers; ++l) MDP_REQUIRE(d->mlp_act[l] >= 0 && d->mlp_act[l] <= 5, "bad activation id");
+    return MDP_OK;
+}
+
+MDP_DEV float act_fn(float x, int a) {
+    switch (a) {
+        case 1: return x > 0.0f ? x : (expf(x) - 1.0f);          // elu (alpha 1)
+        case 2: return x > 0.0f ? x : 0.0f;                      // relu
+        case 3: return tanhf(x);
+        case 4: return x / (1.0f + fabsf(x));                    // softsign
+        case 5: return 1.0f / (1.0f + expf(-x));                 // sigmoid
+        default: return x;
+    }
+}
+MDP_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct NetDev {
+    mdp_net_desc_t d;
+    NetLayout L;
+};
+
+MDP_DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+MDP_DEV f32x4 load_bias(const float* lds, int off, int t, int lane) {
+    f32x4 v;
+    v[0] = lds[off + (t * 4 + 0) * 64 + lane];
+    v[1] = lds[off + (t * 4 + 1) * 64 + lane];
+    v[2] = lds[off + (t * 4 + 2) * 64 + lane];
+    v[3] = lds[off + (t * 4 + 3) * 64 + lane];
+    return v;
+}
+
+// Runs the MLP part.  in_first[]: B operands of the first layer's k-steps (count = mlp_ksteps[0] <= 8).
+// Returns the scalar network output in lanes with gq == 0 (D tile 0, row 0).
+MDP_DEV float run_mlp(const NetDev& net, const float* lds, int lane, const float (&in_first)[8]) {
+    float cur[MLP_NT * 4];  // layer outputs: register r of tile t -> cur[t*4 + r]
+#pragma unroll
+    for (int i = 0; i < MLP_NT * 4; ++i) cur[i] = 0.0f;
+#pragma unroll
+    for (int l = 0; l < MAX_MLP_LAYERS; ++l) {
+        if (l < net.d.mlp_layers) {
+            int nt_out = (net.d.mlp_dims[l + 1] + 15) / 16;
+            f32x4 acc[MLP_NT];
+#pragma unroll
+            for (int t = 0; t < MLP_NT; ++t) acc[t] = load_bias(lds, net.L.mlp_b[l], t, lane);
+            int ks = net.L.mlp_ksteps[l];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (s < ks) {
+                    float b = (l == 0) ? in_first[s] : cur[s];
+#pragma unroll
+                    for (int t = 0; t < MLP_NT; ++t)
+                        if (t < nt_out) acc[t] = mfma4(lds[net.L.mlp_w[l] + (s * MLP_NT + t) * 64 + lane], b, acc[t]);
+                }
+            }
+            int a = net.d.mlp_act[l];
+#pragma unroll
+            for (int t = 0; t < MLP_NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cur[t * 4 + r] = act_fn(acc[t][r], a);
+        }
+    }
+    return cur[0];
+}
+
+MDP_DEV void dc_clip_store(float tau, float qd, int64_t row, const float* __restrict__ eff_lim,
+                           const float* __restrict__ vel_lim, float sat, float* __restrict__ computed,
+                           float* __restrict__ applied) {
+    float lim = eff_lim[row], vl = vel_lim[row];
+    float mx = tclamp(sat * (1.0f - qd / vl), 0.0f, lim);
+    float mn = tclamp(sat * (-1.0f - qd / vl), -lim, 0.0f);
+    computed[row] = tau;
+    applied[row] = tclamp(tau, mn, mx);
+}
+
+template <int H>
+__global__ void __launch_bounds__(256)
+k_lstm(NetDev net, const float* __restrict__ packed, int64_t rows, int J,
+       const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
+       const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
+       const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
+       float* __restrict__ computed, float* __restrict__ applied) {
+    constexpr int TPL = H / 4;
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < net.L.total; i += blockDim.x) lds[i] = packed[i];
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    int gq = lane >> 4, col = lane & 15;
+    int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    int64_t ngroups = (rows + 15) / 16;
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        int64_t row = g * 16 + col;
+        bool valid = row < rows;
+        int64_t rr = valid ? row : rows - 1;
+        int64_t e = rr / J;
+        int j = (int)(rr - e * J);
+        // actuator_net.py:80-81
+        float x0 = q_des[e * ld_q_des + j] - q[e * ld_q + j];
+        float x1 = qd[e * ld_qd + j];
+        float xin = gq == 0 ? x0 : (gq == 1 ? x1 : 0.0f);
+        float prev[TPL];
+#pragma unroll
+        for (int s = 0; s < TPL; ++s) prev[s] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+            if (l < net.d.lstm_layers) {
+                f32x4 acc[TPL];
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) acc[t] = load_bias(lds, net.L.lstm_b[l], t, lane);
+                const float* w = lds + net.L.lstm_w[l];
+                int ks_in = net.L.lstm_ksteps_in[l];
+                if (l == 0) {
+#pragma unroll
+                    for (int t = 0; t < TPL; ++t) acc[t] = mfma4(w[t * 64 + lane], xin, acc[t]);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < TPL; ++s)
+#pragma unroll
+                        for (int t = 0; t < TPL; ++t) acc[t] = mfma4(w[(s * TPL + t) * 64 + lane], prev[s], acc[t]);
+                }
+                // recurrent part: this lane holds units gq*TPL .. gq*TPL+TPL-1 of row `col`
+                int64_t sbase = ((int64_t)l * rows + rr) * H + gq * TPL;
+                float hl[TPL], cl[TPL];
+#pragma unroll
+                for (int s = 0; s < TPL; ++s) { hl[s] = hs[sbase + s]; cl[s] = cs[sbase + s]; }
+#pragma unroll
+                for (int s = 0; s < TPL; ++s)
+#pragma unroll
+                    for (int t = 0; t < TPL; ++t)
+                        acc[t] = mfma4(w[((ks_in + s) * TPL + t) * 64 + lane], hl[s], acc[t]);
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) {
+                    float ig = sigmoidf_(acc[t][0]);
+                    float fg = sigmoidf_(acc[t][1]);
+                    float gg = tanhf(acc[t][2]);
+                    float og = sigmoidf_(acc[t][3]);
+                    float cn = fg * cl[t] + ig * gg;
+                    float hn = og * tanhf(cn);
+                    prev[t] = hn;
+                    if (valid) { hs[sbase + t] = hn; cs[sbase + t] = cn; }
+                }
+            }
+        }
+        float in_first[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) in_first[s] = s < TPL ? prev[s < TPL ? s : 0] : 0.0f;
+        float tau = run_mlp(net, lds, lane, in_first);
+        if (valid && gq == 0) dc_clip_store(tau, x1, row, eff_lim, vel_lim, sat, computed, applied);
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_mlp(NetDev net, const float* __restrict__ packed, int64_t rows, int J, int Hlen,
+      const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
+      const float* __restrict__ qd, int ld_qd, float* __restrict__ pos_hist, float* __restrict__ vel_hist,
+      const int32_t* __restrict__ input_idx, int n_idx, int order, float pos_scale, float vel_scale,
+      float torque_scale, const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
+      float* __restrict__ computed, float* __restrict__ applied) {
+    extern __shared__ float lds[];
+    for (int i = threadIdx.x; i < net.L.total; i += blockDim.x) lds[i] = packed[i];
+    __syncthreads();
+    int lane = threadIdx.x & 63;
+    int gq = lane >> 4, col = lane & 15;
+    int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    int64_t ngroups = (rows + 15) / 16;
+    int F = 2 * n_idx;
+    for (int64_t g = wave; g < ngroups; g += nwaves) {
+        int64_t row = g * 16 + col;
+        bool valid = row < rows;
+        int64_t rr = valid ? row : rows - 1;
+        int64_t e = rr / J;
+        int j = (int)(rr - e * J);
+        float perr = q_des[e * ld_q_des + j] - q[e * ld_q + j];  // actuator_net.py:153
+        float vel = qd[e * ld_qd + j];
+        // features 4*s + gq of the rolled histories (new[0] = current, new[h] = old[h-1])
+        float in_first[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            int f = 4 * s + gq;
+            float v = 0.0f;
+            if (f < F) {
+                bool first_half = f < n_idx;
+                bool is_pos = (order == 0) ? first_half : !first_half;
+                int tap = input_idx[first_half ? f : f - n_idx];
+                const float* hist = is_pos ? pos_hist : vel_hist;
+                float raw = tap == 0 ? (is_pos ? perr : vel) : hist[(e * Hlen + (tap - 1)) * J + j];
+                v = raw * (is_pos ? pos_scale : vel_scale);
+            }
+            in_first[s] = v;
+        }
+        float tau = run_mlp(net, lds, lane, in_first) * torque_scale;
+        if (valid && gq == 0) {
+            dc_clip_store(tau, vel, row, eff_lim, vel_lim, sat, computed, applied);
+            // roll by one (actuator_net.py:152-156); all taps above were consumed by the MFMA chain
+            for (int h = Hlen - 1; h >= 1; --h) {
+                pos_hist[(e * Hlen + h) * J + j] = pos_hist[(e * Hlen + h - 1) * J + j];
+                vel_hist[(e * Hlen + h) * J + j] = vel_hist[(e * Hlen + h - 1) * J + j];
+            }
+            pos_hist[(e * Hlen) * J + j] = perr;
+            vel_hist[(e * Hlen) * J + j] = vel;
+        }
+    }
+}
+
+__global__ void k_lstm_reset(int L, int H, int N, int J, float* __restrict__ hs, float* __restrict__ cs,
+                             const uint8_t* __restrict__ mask) {
+    int64_t per_layer = (int64_t)N * J * H;
+    int64_t total = per_layer * L;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t within = i % per_layer;
+        int e = (int)(within / ((int64_t)J * H));
+        if (mask && !mask[e]) continue;
+        hs[i] = 0.0f;
+        cs[i] = 0.0f;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t mdp_net_packed_size(const mdp_net_desc_t* desc) {
+    if (validate(desc) != MDP_OK) return -1;
+    NetLayout L;
+    return make_layout(*desc, L);
+}
+
+extern "C" int mdp_net_pack(const mdp_net_desc_t* desc, const float* const* weights, float* out) {
+    int rc = validate(desc);
+    if (rc != MDP_OK) return rc;
+    MDP_REQUIRE(weights && out, "null pointer");
+    const mdp_net_desc_t& d = *desc;
+    NetLayout L;
+    int total = make_layout(d, L);
+    for (int i = 0; i < total; ++i) out[i] = 0.0f;
+    int H = d.lstm_hidden, TPL = H > 0 ? H / 4 : 0;
+    int wi = 0;
+    for (int l = 0; l < d.lstm_layers; ++l) {
+        int in_dim = l == 0 ? d.lstm_input : H;
+        const float* w_ih = weights[wi++];
+        const float* w_hh = weights[wi++];
+        const float* b_ih = weights[wi++];
+        const float* b_hh = weights[wi++];
+        int ks_in = L.lstm_ksteps_in[l];
+        for (int t = 0; t < TPL; ++t)
+            for (int lane = 0; lane < 64; ++lane) {
+                int m = lane & 15, kq = lane >> 4;
+                int gq = m >> 2, r = m & 3;
+                int grow = r * H + gq * TPL + t;  // PyTorch gate row (i,f,g,o blocks)
+                // input k-steps
+                for (int s = 0; s < ks_in; ++s) {
+                    int in_idx = (l == 0) ? (4 * s + kq) : (kq * TPL + s);
+                    float v = in_idx < in_dim ? w_ih[(int64_t)grow * in_dim + in_idx] : 0.0f;
+                    out[L.lstm_w[l] + (s * TPL + t) * 64 + lane] = v;
+                }
+                for (int s = 0; s < TPL; ++s)
+                    out[L.lstm_w[l] + ((ks_in + s) * TPL + t) * 64 + lane] = w_hh[(int64_t)grow * H + kq * TPL + s];
+            }
+        // bias fragments follow the D layout: lane (gq = lane>>4), register r
+        for (int t = 0; t < TPL; ++t)
+            for (int r = 0; r < 4; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int gq = lane >> 4;
+                    int grow = r * H + gq * TPL + t;
+                    out[L.lstm_b[l] + (t * 4 + r) * 64 + lane] = b_ih[grow] + b_hh[grow];
+                }
+    }
+    for (int l = 0; l < d.mlp_layers; ++l) {
+        int in_dim = d.mlp_dims[l], out_dim = d.mlp_dims[l + 1];
+        const float* w = weights[wi++];
+        const float* b = weights[wi++];
+        int ks = L.mlp_ksteps[l];
+        for (int s = 0; s < ks; ++s)
+            for (int t = 0; t < MLP_NT; ++t)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int m = lane & 15, kq = lane >> 4;
+                    int o = 16 * t + m;
+                    int in_idx;
+                    if (l == 0 && d.lstm_layers > 0) in_idx = kq * TPL + s;       // LSTM unit held by quad kq, slot s
+                    else if (l == 0) in_idx = 4 * s + kq;                         // raw feature order
+                    else in_idx = 16 * (s / 4) + 4 * kq + (s % 4);                // D layout of the previous layer
+                    float v = (o < out_dim && in_idx < in_dim) ? w[(int64_t)o * in_dim + in_idx] : 0.0f;
+                    out[L.mlp_w[l] + (s * MLP_NT + t) * 64 + lane] = v;
+                }
+        for (int t = 0; t < MLP_NT; ++t)
+            for (int r = 0; r < 4; ++r)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int o = 16 * t + 4 * (lane >> 4) + r;
+                    out[L.mlp_b[l] + (t * 4 + r) * 64 + lane] = o < out_dim ? b[o] : 0.0f;
+                }
+    }
+    return MDP_OK;
+}
+
+static unsigned net_grid(int64_t rows) {
+    int64_t groups = (rows + 15) / 16;
+    int64_t blocks = (groups + 3) / 4;  // 4 waves per block
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+extern "C" int mdp_actuator_lstm_compute(const mdp_net_desc_t* desc, const float* packed_weights, int num_envs,
+                                         int num_joints, const float* q_des, int ld_q_des, const float* joint_pos,
+                                         int ld_pos, const float* joint_vel, int ld_vel, float* hidden_state,
+                                         float* cell_state, const float* effort_limit, const float* velocity_limit,
+                                         float saturation_effort, float* computed_effort, float* applied_effort,
+                                         void* stream) {
+    int rc = validate(desc);
+    if (rc != MDP_OK) return rc;
+    MDP_REQUIRE(desc->lstm_layers >= 1, "not an LSTM network");
+    MDP_REQUIRE(packed_weights && q_des && joint_pos && joint_vel && hidden_state && cell_state && effort_limit &&
+                    velocity_limit && computed_effort && applied_effort,
+                "null pointer");
+    int64_t rows = (int64_t)num_envs * num_joints;
+    if (rows == 0) return MDP_OK;
+    NetDev net;
+    net.d = *desc;
+    make_layout(*desc, net.L);
+    size_t lds_bytes = (size_t)net.L.total * sizeof(float);
+    MDP_REQUIRE(lds_bytes <= 150 * 1024, "network too large for LDS staging (%zu bytes)", lds_bytes);
+    dim3 grid(net_grid(rows)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH(HH)                                                                                                 \
+    do {                                                                                                           \
+        if (lds_bytes > 64 * 1024)                                                                                 \
+            MDP_CHECK_HIP(hipFuncSetAttribute((const void*)k_lstm<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                              (int)lds_bytes));                                                    \
+        hipLaunchKernelGGL(k_lstm<HH>, grid, block, lds_bytes, s, net, packed_weights, rows, num_joints, q_des,    \
+                           ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, \
+                           velocity_limit, saturation_effort, computed_effort, applied_effort);                    \
+    } while (0)
+    switch (desc->lstm_hidden) {
+        case 8: LAUNCH(8); break;
+        case 16: LAUNCH(16); break;
+        case 32: LAUNCH(32); break;
+        default: return fail(MDP_ERR_UNSUPPORTED, "lstm hidden %d", desc->lstm_hidden);
+    }
+#undef LAUNCH
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_actuator_lstm_reset(int layers, int hidden, int num_envs, int num_joints, float* hidden_state,
+                                       float* cell_state, const uint8_t* env_mask, void* stream) {
+    MDP_REQUIRE(hidden_state && cell_state, "null pointer");
+    int64_t total = (int64_t)layers * num_envs * num_joints * hidden;
+    if (total == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_lstm_reset, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), layers, hidden,
+                       num_envs, num_joints, hidden_state, cell_state, env_mask);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_actuator_mlp_compute(const mdp_net_desc_t* desc, const float* packed_weights, int num_envs,
+                                        int num_joints, int history_len, const float* q_des, int ld_q_des,
+                                        const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                        float* pos_err_history, float* vel_history, const int32_t* input_idx,
+                                        int n_idx, int input_order, float pos_scale, float vel_scale,
+                                        float torque_scale, const float* effort_limit, const float* velocity_limit,
+                                        float saturation_effort, float* computed_effort, float* applied_effort,
+                                        void* stream) {
+    int rc = validate(desc);
+    if (rc != MDP_OK) return rc;
+    MDP_REQUIRE(desc->lstm_layers == 0, "not a pure MLP network");
+    MDP_REQUIRE(n_idx >= 1 && 2 * n_idx == desc->mlp_dims[0], "network input width %d != 2*len(input_idx)=%d",
+                desc->mlp_dims[0], 2 * n_idx);
+    MDP_REQUIRE(input_order == 0 || input_order == 1,
+                "Invalid input order for MLP actuator net. Must be 'pos_vel' or 'vel_pos'.");
+    MDP_REQUIRE(packed_weights && q_des && joint_pos && joint_vel && pos_err_history && vel_history && input_idx &&
+                    effort_limit && velocity_limit && computed_effort && applied_effort,
+                "null pointer");
+    int64_t rows = (int64_t)num_envs * num_joints;
+    if (rows == 0) return MDP_OK;
+    NetDev net;
+    net.d = *desc;
+    make_layout(*desc, net.L);
+    size_t lds_bytes = (size_t)net.L.total * sizeof(float);
+    hipLaunchKernelGGL(k_mlp, dim3(net_grid(rows)), dim3(256), lds_bytes, as_stream(stream), net, packed_weights,
+                       rows, num_joints, history_len, q_des, ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel,
+                       pos_err_history, vel_history, input_idx, n_idx, input_order, pos_scale, vel_scale,
+                       torque_scale, effort_limit, velocity_limit, saturation_effort, computed_effort,
+                       applied_effort);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}

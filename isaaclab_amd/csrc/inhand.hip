@@ -1,0 +1,241 @@
+// Shadow-hand in-hand cube reorientation (direct workflow).
+// Reference: TASKS/direct/inhand_manipulation/inhand_manipulation_env.py:97-117,179-199,262-433
+#include "mdp_device.hpp"
+#include "mdp_host.hpp"
+
+using namespace mdp;
+
+namespace {
+
+// :353-355 scale, :358-360 unscale
+MDP_DEV float ih_scale(float x, float lower, float upper) { return 0.5f * (x + 1.0f) * (upper - lower) + lower; }
+MDP_DEV float ih_unscale(float x, float lower, float upper) { return ((2.0f * x - upper) - lower) / (upper - lower); }
+
+// :370-374 rotation_distance
+MDP_DEV float rotation_distance(Q4 obj, Q4 target) {
+    Q4 d = quat_mul(obj, quat_conjugate(target));
+    float n = norm3(V3{d.x, d.y, d.z});
+    return 2.0f * asinf(tclamp_max(n, 1.0f));
+}
+
+// :97-117, one thread per (env, actuated joint)
+__global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ actions,
+                               const int32_t* __restrict__ act_idx, const float* __restrict__ lower,
+                               const float* __restrict__ upper, float* __restrict__ cur, float* __restrict__ prev) {
+    int64_t total = (int64_t)cfg.num_envs * cfg.num_actuated;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = i / cfg.num_actuated;
+        int a = (int)(i - e * cfg.num_actuated);
+        int j = act_idx[a];
+        int64_t o = e * cfg.num_dofs + j;
+        float lo = lower[o], hi = upper[o];
+        float t = ih_scale(actions[i], lo, hi);
+        t = cfg.act_moving_average * t + (1.0f - cfg.act_moving_average) * prev[o];
+        t = tmax(tmin(t, hi), lo);  // math.py:64-78 saturate
+        cur[o] = t;
+        prev[o] = t;
+    }
+}
+
+// :179-199
+__global__ void k_dones(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, const float* __restrict__ origins,
+                        const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
+                        const float* __restrict__ successes, int64_t* __restrict__ ep_len,
+                        uint8_t* __restrict__ out_of_reach, uint8_t* __restrict__ time_out) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= cfg.num_envs) return;
+    const float* r = obj + 13 * (int64_t)e;
+    V3 pos{r[0] - origins[3 * e], r[1] - origins[3 * e + 1], r[2] - origins[3 * e + 2]};
+    V3 d{pos.x - in_hand[3 * e], pos.y - in_hand[3 * e + 1], pos.z - in_hand[3 * e + 2]};
+    float goal_dist = norm3(d);
+    out_of_reach[e] = goal_dist >= cfg.fall_dist ? 1 : 0;
+    int64_t len = ep_len[e];
+    bool max_succ = false;
+    if (cfg.max_consecutive_success > 0) {
+        float rot_dist = rotation_distance(ld4(r + 3), ld4(goal_rot + 4 * (int64_t)e));
+        if (fabsf(rot_dist) <= cfg.success_tolerance) { len = 0; ep_len[e] = 0; }
+        max_succ = successes[e] >= (float)cfg.max_consecutive_success;
+    }
+    bool to = len >= cfg.max_episode_length - 1;
+    time_out[e] = (to || max_succ) ? 1 : 0;
+}
+
+// :377-433 per-env part; cross-env sums accumulated per block then atomically in fp64
+__global__ void k_rewards(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, const float* __restrict__ origins,
+                          const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
+                          const float* __restrict__ actions, const uint8_t* __restrict__ reset_buf,
+                          const uint8_t* __restrict__ reset_goal_buf, float* __restrict__ successes,
+                          float* __restrict__ reward, uint8_t* __restrict__ goal_resets,
+                          double* __restrict__ partials) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double my_resets = 0.0, my_succ = 0.0;
+    if (e < cfg.num_envs) {
+        const float* r = obj + 13 * (int64_t)e;
+        V3 pos{r[0] - origins[3 * e], r[1] - origins[3 * e + 1], r[2] - origins[3 * e + 2]};
+        V3 d{pos.x - in_hand[3 * e], pos.y - in_hand[3 * e + 1], pos.z - in_hand[3 * e + 2]};
+        float goal_dist = norm3(d);
+        float rot_dist = rotation_distance(ld4(r + 3), ld4(goal_rot + 4 * (int64_t)e));
+        float dist_rew = goal_dist * cfg.dist_reward_scale;
+        float rot_rew = 1.0f / (fabsf(rot_dist) + cfg.rot_eps) * cfg.rot_reward_scale;
+        float ap = 0.0f;
+        int A = cfg.num_actuated;
+        for (int k = 0; k < A; ++k) { float a = actions[(int64_t)e * A + k]; ap += a * a; }
+        float rew = (dist_rew + rot_rew) + ap * cfg.action_penalty_scale;
+        uint8_t gr = (fabsf(rot_dist) <= cfg.success_tolerance) ? 1 : reset_goal_buf[e];
+        float succ = successes[e] + (float)gr;
+        if (gr == 1) rew = rew + cfg.reach_goal_bonus;
+        bool fell = goal_dist >= cfg.fall_dist;
+        if (fell) rew = rew + cfg.fall_penalty;
+        uint8_t resets = fell ? 1 : reset_buf[e];
+        successes[e] = succ;
+        reward[e] = rew;
+        goal_resets[e] = gr;
+        my_resets = (double)resets;
+        my_succ = (double)(succ * (float)resets);
+    }
+    // wave reduction then one fp64 atomic pair per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        my_resets += __shfl_down(my_resets, off);
+        my_succ += __shfl_down(my_succ, off);
+    }
+    if ((threadIdx.x & 63) == 0 && (my_resets != 0.0 || my_succ != 0.0)) {
+        atomicAdd(&partials[0], my_resets);
+        atomicAdd(&partials[1], my_succ);
+    }
+}
+
+__global__ void k_finish_rewards(mdp_inhand_cfg_t cfg, const double* __restrict__ partials,
+                                 float* __restrict__ cons) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float num_resets = (float)partials[0];
+        float finished = (float)partials[1];
+        if (num_resets > 0.0f)
+            cons[0] = cfg.av_factor * finished / num_resets + (1.0f - cfg.av_factor) * cons[0];
+    }
+}
+
+// :298-322, one thread per (env, column); block owns whole envs
+__global__ void k_full_obs(mdp_inhand_cfg_t cfg, const float* __restrict__ q, const float* __restrict__ qd,
+                           const float* __restrict__ lower, const float* __restrict__ upper,
+                           const float* __restrict__ obj, const float* __restrict__ origins,
+                           const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
+                           const float* __restrict__ body, const int32_t* __restrict__ fingers,
+                           const float* __restrict__ actions, int A, float* __restrict__ obs, int ld_obs, int O) {
+    int D = cfg.num_dofs, F = cfg.num_fingertips, B = cfg.num_bodies;
+    int64_t total = (int64_t)cfg.num_envs * O;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e = i / O;
+        int c = (int)(i - e * O);
+        const float* r = obj + 13 * e;
+        float v;
+        int k = c;
+        if (k < D) {
+            v = ih_unscale(q[e * D + k], lower[e * D + k], upper[e * D + k]);
+        } else if ((k -= D) < D) {
+            v = cfg.vel_obs_scale * qd[e * D + k];
+        } else if ((k -= D) < 3) {
+            v = r[k] - origins[3 * e + k];  // object_pos
+        } else if ((k -= 3) < 4) {
+            v = r[3 + k];  // object_rot
+        } else if ((k -= 4) < 3) {
+            v = r[7 + k];  // object_linvel
+        } else if ((k -= 3) < 3) {
+            v = cfg.vel_obs_scale * r[10 + k];
+        } else if ((k -= 3) < 3) {
+            v = in_hand[3 * e + k];
+        } else if ((k -= 3) < 4) {
+            v = goal_rot[4 * e + k];
+        } else if ((k -= 4) < 4) {
+            v = get(quat_mul(ld4(r + 3), quat_conjugate(ld4(goal_rot + 4 * e))), k);
+        } else if ((k -= 4) < 3 * F) {
+            int f = k / 3, a = k - 3 * f;
+            v = body[(e * B + fingers[f]) * 13 + a] - origins[3 * e + a];
+        } else if ((k -= 3 * F) < 4 * F) {
+            int f = k / 4, a = k - 4 * f;
+            v = body[(e * B + fingers[f]) * 13 + 3 + a];
+        } else if ((k -= 4 * F) < 6 * F) {
+            int f = k / 6, a = k - 6 * f;
+            v = body[(e * B + fingers[f]) * 13 + 7 + a];
+        } else {
+            k -= 6 * F;
+            v = actions[e * A + k];
+        }
+        obs[e * ld_obs + c] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int mdp_inhand_apply_action(const mdp_inhand_cfg_t* cfg, const float* actions,
+                                       const int32_t* actuated_idx, const float* lower, const float* upper,
+                                       float* cur_targets, float* prev_targets, void* stream) {
+    MDP_REQUIRE(cfg && actions && actuated_idx && lower && upper && cur_targets && prev_targets, "null pointer");
+    int64_t total = (int64_t)cfg->num_envs * cfg->num_actuated;
+    if (total == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_apply_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, actions,
+                       actuated_idx, lower, upper, cur_targets, prev_targets);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_dones(const mdp_inhand_cfg_t* cfg, const float* object_root_state, const float* env_origins,
+                                const float* in_hand_pos, const float* goal_rot, const float* successes,
+                                int64_t* episode_length_buf, uint8_t* out_of_reach, uint8_t* time_out, void* stream) {
+    MDP_REQUIRE(cfg && object_root_state && env_origins && in_hand_pos && goal_rot && successes &&
+                    episode_length_buf && out_of_reach && time_out,
+                "null pointer");
+    if (cfg->num_envs == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_dones, dim3(grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), *cfg,
+                       object_root_state, env_origins, in_hand_pos, goal_rot, successes, episode_length_buf,
+                       out_of_reach, time_out);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_rewards(const mdp_inhand_cfg_t* cfg, const float* object_root_state,
+                                  const float* env_origins, const float* in_hand_pos, const float* goal_rot,
+                                  const float* actions, const uint8_t* reset_buf, const uint8_t* reset_goal_buf,
+                                  float* successes, float* reward, uint8_t* goal_resets, double* partials,
+                                  void* stream) {
+    MDP_REQUIRE(cfg && object_root_state && env_origins && in_hand_pos && goal_rot && actions && reset_buf &&
+                    reset_goal_buf && successes && reward && goal_resets && partials,
+                "null pointer");
+    if (cfg->num_envs == 0) return MDP_OK;
+    hipStream_t s = as_stream(stream);
+    MDP_CHECK_HIP(hipMemsetAsync(partials, 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_rewards, dim3(grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0, s, *cfg,
+                       object_root_state, env_origins, in_hand_pos, goal_rot, actions, reset_buf, reset_goal_buf,
+                       successes, reward, goal_resets, partials);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_finish_rewards(const mdp_inhand_cfg_t* cfg, const double* partials,
+                                         float* consecutive_successes, void* stream) {
+    MDP_REQUIRE(cfg && partials && consecutive_successes, "null pointer");
+    hipLaunchKernelGGL(k_finish_rewards, dim3(1), dim3(64), 0, as_stream(stream), *cfg, partials,
+                       consecutive_successes);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joint_pos, const float* joint_vel,
+                                   const float* lower, const float* upper, const float* object_root_state,
+                                   const float* env_origins, const float* in_hand_pos, const float* goal_rot,
+                                   const float* body_state_w, const int32_t* finger_bodies, const float* actions,
+                                   int action_dim, float* obs, int ld_obs, void* stream) {
+    MDP_REQUIRE(cfg && joint_pos && joint_vel && lower && upper && object_root_state && env_origins && in_hand_pos &&
+                    goal_rot && body_state_w && finger_bodies && actions && obs,
+                "null pointer");
+    int O = 2 * cfg->num_dofs + 13 + 11 + 13 * cfg->num_fingertips + action_dim;
+    MDP_REQUIRE(ld_obs >= O, "obs buffer too narrow (%d < %d)", ld_obs, O);
+    int64_t total = (int64_t)cfg->num_envs * O;
+    if (total == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_full_obs, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, joint_pos,
+                       joint_vel, lower, upper, object_root_state, env_origins, in_hand_pos, goal_rot, body_state_w,
+                       finger_bodies, actions, action_dim, obs, ld_obs, O);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}

@@ -1,0 +1,739 @@
+// Fused manager-term programs: one kernel per manager evaluates every lowered term.
+// Reference: LAB/managers/observation_manager.py:260-335, reward_manager.py:128-157,
+// termination_manager.py:151-174 and the term libraries LAB/envs/mdp/{observations,rewards,
+// terminations}.py, TASKS/manager_based/locomotion/velocity/mdp/{rewards,terminations}.py.
+//
+// Layout: the reference API hands out row-major (N, .) tensors, so the kernels keep that layout and
+// get coalescing from the thread mapping instead: the observation kernel maps a thread to one
+// (env, column) pair with columns fastest (a block owns whole environments: contiguous row writes),
+// reward / termination kernels map a thread to one env and walk short rows (J <= 32) serially.
+#include "mdp_device.hpp"
+#include "mdp_host.hpp"
+#include "raycast_device.hpp"
+#include "mesh_handle.hpp"
+#include "term_ops.h"
+
+#include <vector>
+
+using namespace mdp;
+
+struct RayAux {
+    mdp_mesh_view_t mesh;
+    mdp_raycaster_desc_t d;
+};
+
+struct mdp_program {
+    int kind = 0, device = 0, num_envs = 0, num_terms = 0;
+    mdp_term_t* d_terms = nullptr;
+    int32_t* d_pool = nullptr;
+    RayAux* d_aux = nullptr;
+    int16_t* d_col2term = nullptr;
+    uint64_t* d_rng = nullptr;  // {seed, epoch, ticket, pad}
+    int total_cols = 0;
+    int uses_rng = 0;
+    int has_cast = 0;
+    std::vector<mdp_term_t> h_terms;
+};
+
+namespace {
+
+MDP_DEV int idx_at(const mdp_term_t& t, const int32_t* __restrict__ pool, int k) {
+    return t.n_idx < 0 ? k : pool[t.idx_offset + k];
+}
+MDP_DEV int idx2_at(const mdp_term_t& t, const int32_t* __restrict__ pool, int k) {
+    return t.n_idx2 < 0 ? k : pool[t.idx2_offset + k];
+}
+// number of reduced elements: explicit list length, or the full width stored in i1 for "all"
+MDP_DEV int red_count(const mdp_term_t& t, int full) { return t.n_idx < 0 ? full : t.n_idx; }
+
+// max over history of |f| for body b: hist (N,H,B,3)
+MDP_DEV float contact_hist_max(const float* __restrict__ hist, int e, int H, int B, int b) {
+    float m = 0.0f;
+    for (int h = 0; h < H; ++h) {
+        const float* f = hist + (((int64_t)e * H + h) * B + b) * 3;
+        float n = norm3(ld3(f));
+        m = (h == 0) ? n : tmax(m, n);
+    }
+    return m;
+}
+
+// =============================================================================================
+// Observations
+// =============================================================================================
+struct CastCtx {
+    bool outdated;
+};
+
+MDP_DEV float obs_value(const mdp_term_t& t, const int32_t* __restrict__ pool, int e, int k) {
+    switch (t.op) {
+        case MDP_OBS_COPY: {
+            const float* p = (const float*)t.p0;
+            return p[(int64_t)e * t.i0 + t.i1 + idx_at(t, pool, k)];
+        }
+        case MDP_OBS_SUB: {
+            const float* p = (const float*)t.p0;
+            const float* q = (const float*)t.p1;
+            int j = idx_at(t, pool, k);
+            return p[(int64_t)e * t.i0 + t.i1 + j] - q[(int64_t)e * t.i2 + t.i3 + j];
+        }
+        case MDP_OBS_ADD_ROW_BIAS: {
+            const float* p = (const float*)t.p0;
+            const float* q = (const float*)t.p1;
+            return p[(int64_t)e * t.i0 + t.i1 + idx_at(t, pool, k)] + q[(int64_t)e * t.i2 + t.i3];
+        }
+        case MDP_OBS_BASE_LIN_VEL:
+        case MDP_OBS_BASE_ANG_VEL: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            V3 v = ld3(r + (t.op == MDP_OBS_BASE_LIN_VEL ? 7 : 10));
+            return get(quat_rotate_inverse(ld4(r + 3), v), k);
+        }
+        case MDP_OBS_PROJECTED_GRAVITY: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            return get(quat_rotate_inverse(ld4(r + 3), V3{t.f0, t.f1, t.f2}), k);
+        }
+        case MDP_OBS_ROOT_QUAT_UNIQUE: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            float w = r[3];
+            float v = r[3 + k];
+            return w < 0.0f ? -v : v;
+        }
+        case MDP_OBS_JOINT_POS_LIMIT_NORMALIZED: {
+            // math.py:22-40 scale_transform
+            int j = idx_at(t, pool, k);
+            float x = ((const float*)t.p0)[(int64_t)e * t.i0 + j];
+            const float* lim = (const float*)t.p1 + ((int64_t)e * t.i1 + j) * 2;
+            float lower = lim[0], upper = lim[1];
+            float offset = (lower + upper) * 0.5f;
+            return 2.0f * (x - offset) / (upper - lower);
+        }
+        case MDP_OBS_HEIGHT_SCAN: {
+            const float* pos = (const float*)t.p0;
+            const float* hits = (const float*)t.p1;
+            return (pos[3 * (int64_t)e + 2] - hits[((int64_t)e * t.i0 + k) * 3 + 2]) - t.f0;
+        }
+        default: return 0.0f;
+    }
+}
+
+MDP_DEV float obs_height_scan_cast(const mdp_term_t& t, int e, int k, bool od) {
+    const RayAux* a = (const RayAux*)t.p4;
+    const mdp_raycaster_desc_t& d = a->d;
+    const float inf = __builtin_inff();
+    int R = d.num_rays;
+    float* o = d.ray_hits_w + ((int64_t)e * R + k) * 3;
+    if (!od) return (d.pos_w[3 * (int64_t)e + 2] - o[2]) - t.f0;
+    const float* p = d.root_pose + (int64_t)e * d.ld_pose;
+    V3 pos = ld3(p);
+    if (d.drift) { pos.x += d.drift[3 * e]; pos.y += d.drift[3 * e + 1]; pos.z += d.drift[3 * e + 2]; }
+    Q4 q = ld4(p + 3);
+    Q4 qr = d.attach_yaw_only ? yaw_quat(q) : q;
+    V3 s = quat_apply(qr, ld3(d.ray_starts_local + 3 * k));
+    s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
+    V3 dir = ld3(d.ray_dirs_local + 3 * k);
+    if (!d.attach_yaw_only) dir = quat_apply(q, dir);
+    mdp_ray_t ray = mdp_rc_make_ray(s.x, s.y, s.z, dir.x, dir.y, dir.z);
+    mdp_hit_t h = mdp_rc_query(&a->mesh, &ray, d.max_dist, a->mesh.accel);
+    float hz;
+    if (h.face >= 0) {
+        o[0] = s.x + h.t * dir.x; o[1] = s.y + h.t * dir.y; hz = s.z + h.t * dir.z; o[2] = hz;
+    } else {
+        o[0] = inf; o[1] = inf; o[2] = inf; hz = inf;
+    }
+    return (pos.z - hz) - t.f0;
+}
+
+MDP_DEV void obs_cast_commit(const mdp_term_t& t, int e) {
+    const RayAux* a = (const RayAux*)t.p4;
+    const mdp_raycaster_desc_t& d = a->d;
+    const float* p = d.root_pose + (int64_t)e * d.ld_pose;
+    V3 pos = ld3(p);
+    if (d.drift) { pos.x += d.drift[3 * e]; pos.y += d.drift[3 * e + 1]; pos.z += d.drift[3 * e + 2]; }
+    st3(d.pos_w + 3 * (int64_t)e, pos);
+    st4(d.quat_w + 4 * (int64_t)e, ld4(p + 3));
+    if (d.timestamp_last_update) d.timestamp_last_update[e] = d.timestamp[e];
+    if (d.is_outdated) d.is_outdated[e] = 0;
+}
+
+// observation_manager.py:313-318: noise -> clip -> scale
+MDP_DEV float obs_post(const mdp_term_t& t, float v, int e, int k, uint64_t seed, uint64_t epoch, uint32_t stream,
+                       uint64_t index) {
+    if (t.noise_kind == 1) {
+        float u = t.noise_u ? t.noise_u[(int64_t)e * t.dim + k] : rng_uniform(seed, epoch, stream, index);
+        float n = u * t.n1;  // n1 = (n_max - n_min)
+        if (t.noise_op == 0) v = (v + n) + t.n0;
+        else if (t.noise_op == 1) v = v * (n + t.n0);
+        else v = n + t.n0;
+    } else if (t.noise_kind == 2) {
+        float z = t.noise_u ? t.noise_u[(int64_t)e * t.dim + k] : rng_normal(seed, epoch, stream, index);
+        float n = t.n1 * z;  // std * randn
+        if (t.noise_op == 0) v = (v + t.n0) + n;
+        else if (t.noise_op == 1) v = v * (t.n0 + n);
+        else v = t.n0 + n;
+    } else if (t.noise_kind == 3) {
+        if (t.noise_op == 0) v = v + t.n0;
+        else if (t.noise_op == 1) v = v * t.n0;
+        else v = 0.0f + t.n0;
+    }
+    if (t.has_clip) v = tclamp(v, t.clip_lo, t.clip_hi);
+    if (t.has_scale == 1) v = v * t.scale;
+    else if (t.has_scale == 2) v = v * t.scale_vec[k];
+    return v;
+}
+
+__global__ void k_obs(const mdp_term_t* __restrict__ terms, int T, const int32_t* __restrict__ pool,
+                      const int16_t* __restrict__ col2term, int O, int N, int epb, int slot_w,
+                      float* __restrict__ obs, int ld_obs, uint64_t* rng, int uses_rng, int has_cast) {
+    int le = threadIdx.x / slot_w;
+    int lc = threadIdx.x - le * slot_w;
+    uint64_t seed = 0, epoch = 0;
+    if (uses_rng) { seed = rng[0]; epoch = rng[1]; }
+    for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
+        int e = base + le;
+        bool active = le < epb && e < N;
+        if (active) {
+            for (int c = lc; c < O; c += slot_w) {
+                int ti = col2term[c];
+                const mdp_term_t& t = terms[ti];
+                int k = c - t.out_offset;
+                float v;
+                if (t.op == MDP_OBS_HEIGHT_SCAN_CAST) {
+                    const RayAux* a = (const RayAux*)t.p4;
+                    bool od = a->d.is_outdated ? (a->d.is_outdated[e] != 0) : true;
+                    v = obs_height_scan_cast(t, e, k, od);
+                } else {
+                    v = obs_value(t, pool, e, k);
+                }
+                v = obs_post(t, v, e, k, seed, epoch, 0x4f425300u + (uint32_t)ti, (uint64_t)e * (uint64_t)O + c);
+                obs[(int64_t)e * ld_obs + c] = v;
+            }
+        }
+        if (has_cast) {
+            __syncthreads();  // every ray thread has read the outdated flag before it is cleared
+            if (active && lc == 0) {
+                for (int ti = 0; ti < T; ++ti) {
+                    const mdp_term_t& t = terms[ti];
+                    if (t.op != MDP_OBS_HEIGHT_SCAN_CAST) continue;
+                    const RayAux* a = (const RayAux*)t.p4;
+                    bool od = a->d.is_outdated ? (a->d.is_outdated[e] != 0) : true;
+                    if (od) obs_cast_commit(t, e);
+                }
+            }
+        }
+    }
+    if (uses_rng) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            unsigned long long tk = atomicAdd((unsigned long long*)&rng[2], 1ull);
+            if (tk == (unsigned long long)gridDim.x - 1ull) {
+                rng[2] = 0;
+                rng[1] = epoch + 1;
+            }
+        }
+    }
+}
+
+__global__ void k_obs_post(mdp_term_t t, int N, float* __restrict__ data, int ld, uint64_t seed, uint64_t offset) {
+    int64_t total = (int64_t)N * t.dim;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int e = (int)(i / t.dim);
+        int k = (int)(i - (int64_t)e * t.dim);
+        float v = data[(int64_t)e * ld + k];
+        data[(int64_t)e * ld + k] = obs_post(t, v, e, k, seed, offset, 0x504f5354u, (uint64_t)i);
+    }
+}
+
+// =============================================================================================
+// Rewards
+// =============================================================================================
+MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool, int e, int N) {
+    switch (t.op) {
+        case MDP_REW_EXTERNAL: return ((const float*)t.p0)[(int64_t)e * (t.i0 > 0 ? t.i0 : 1)];
+        case MDP_REW_IS_ALIVE: return ((const uint8_t*)t.p0)[e] ? 0.0f : 1.0f;
+        case MDP_REW_IS_TERMINATED: return ((const uint8_t*)t.p0)[e] ? 1.0f : 0.0f;
+        case MDP_REW_IS_TERMINATED_TERM: {
+            const uint8_t* dones = (const uint8_t*)t.p0;
+            float s = 0.0f;
+            int n = red_count(t, t.i1);
+            for (int k = 0; k < n; ++k) s += dones[(int64_t)idx_at(t, pool, k) * N + e] ? 1.0f : 0.0f;
+            return s * (((const uint8_t*)t.p1)[e] ? 0.0f : 1.0f);
+        }
+        case MDP_REW_LIN_VEL_Z_L2: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            float z = quat_rotate_inverse(ld4(r + 3), ld3(r + 7)).z;
+            return z * z;
+        }
+        case MDP_REW_ANG_VEL_XY_L2: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            V3 w = quat_rotate_inverse(ld4(r + 3), ld3(r + 10));
+            return w.x * w.x + w.y * w.y;
+        }
+        case MDP_REW_FLAT_ORIENTATION_L2: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            V3 g = quat_rotate_inverse(ld4(r + 3), V3{t.f0, t.f1, t.f2});
+            return g.x * g.x + g.y * g.y;
+        }
+        case MDP_REW_BASE_HEIGHT_L2: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            float target = t.f0;
+            if (t.p1) {
+                const float* hits = (const float*)t.p1;
+                int R = t.i1;
+                float s = 0.0f;
+                for (int k = 0; k < R; ++k) s += hits[((int64_t)e * R + k) * 3 + 2];
+                target = t.f0 + s / (float)R;
+            }
+            float d = r[2] - target;
+            return d * d;
+        }
+        case MDP_REW_BODY_LIN_ACC_L2: {
+            const float* acc = (const float*)t.p0;
+            int B = t.i1, n = red_count(t, B);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) s += norm3(ld3(acc + ((int64_t)e * B + idx_at(t, pool, k)) * 6));
+            return s;
+        }
+        case MDP_REW_SUM_SQ: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            int n = red_count(t, t.i1);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) { float v = p[idx_at(t, pool, k)]; s += v * v; }
+            return s;
+        }
+        case MDP_REW_SUM_ABS: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            int n = red_count(t, t.i1);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) s += fabsf(p[idx_at(t, pool, k)]);
+            return s;
+        }
+        case MDP_REW_SUM_ABS_DIFF:
+        case MDP_REW_SUM_SQ_DIFF: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* q = (const float*)t.p1 + (int64_t)e * t.i2;
+            int n = red_count(t, t.i1);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                int j = idx_at(t, pool, k);
+                float d = p[j] - q[j];
+                s += (t.op == MDP_REW_SUM_ABS_DIFF) ? fabsf(d) : d * d;
+            }
+            return s;
+        }
+        case MDP_REW_JOINT_POS_LIMITS: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* lim = (const float*)t.p1 + (int64_t)e * t.i1 * 2;
+            int n = red_count(t, t.i1);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                int j = idx_at(t, pool, k);
+                float o = -tclamp_max(p[j] - lim[2 * j], 0.0f);
+                o = o + tclamp_min(p[j] - lim[2 * j + 1], 0.0f);
+                s += o;
+            }
+            return s;
+        }
+        case MDP_REW_JOINT_VEL_LIMITS: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* lim = (const float*)t.p1 + (int64_t)e * t.i1;
+            int n = red_count(t, t.i1);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                int j = idx_at(t, pool, k);
+                s += tclamp(fabsf(p[j]) - lim[j] * t.f0, 0.0f, 1.0f);
+            }
+            return s;
+        }
+        case MDP_REW_UNDESIRED_CONTACTS:
+        case MDP_REW_CONTACT_FORCES: {
+            const float* hist = (const float*)t.p0;
+            int H = t.i0, B = t.i1, n = red_count(t, B);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                float m = contact_hist_max(hist, e, H, B, idx_at(t, pool, k));
+                if (t.op == MDP_REW_UNDESIRED_CONTACTS) s += (m > t.f0) ? 1.0f : 0.0f;
+                else s += tclamp_min(m - t.f0, 0.0f);
+            }
+            return s;
+        }
+        case MDP_REW_TRACK_LIN_VEL_XY_EXP: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* c = (const float*)t.p1 + (int64_t)e * t.i1;
+            V3 v = quat_rotate_inverse(ld4(r + 3), ld3(r + 7));
+            float dx = c[0] - v.x, dy = c[1] - v.y;
+            float err = dx * dx + dy * dy;
+            return expf(-err / t.f0);
+        }
+        case MDP_REW_TRACK_ANG_VEL_Z_EXP: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* c = (const float*)t.p1 + (int64_t)e * t.i1;
+            V3 w = quat_rotate_inverse(ld4(r + 3), ld3(r + 10));
+            float d = c[2] - w.z;
+            return expf(-(d * d) / t.f0);
+        }
+        case MDP_REW_FEET_AIR_TIME: {
+            const float* tc = (const float*)t.p0 + (int64_t)e * t.i1;
+            const float* la = (const float*)t.p1 + (int64_t)e * t.i1;
+            const float* c = (const float*)t.p2 + (int64_t)e * t.i2;
+            int n = red_count(t, t.i1);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                int b = idx_at(t, pool, k);
+                float first = ((tc[b] > 0.0f) && (tc[b] < t.f1)) ? 1.0f : 0.0f;
+                s += (la[b] - t.f0) * first;
+            }
+            return s * ((norm2(c[0], c[1]) > 0.1f) ? 1.0f : 0.0f);
+        }
+        case MDP_REW_FEET_AIR_TIME_POSITIVE_BIPED: {
+            const float* air = (const float*)t.p0 + (int64_t)e * t.i1;
+            const float* con = (const float*)t.p1 + (int64_t)e * t.i1;
+            const float* c = (const float*)t.p2 + (int64_t)e * t.i2;
+            int n = red_count(t, t.i1);
+            int in_contact = 0;
+            for (int k = 0; k < n; ++k) in_contact += con[idx_at(t, pool, k)] > 0.0f ? 1 : 0;
+            bool single = in_contact == 1;
+            float m = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                int b = idx_at(t, pool, k);
+                float mode = con[b] > 0.0f ? con[b] : air[b];
+                float v = single ? mode : 0.0f;
+                m = (k == 0) ? v : tmin(m, v);
+            }
+            m = tclamp_max(m, t.f0);
+            return m * ((norm2(c[0], c[1]) > 0.1f) ? 1.0f : 0.0f);
+        }
+        case MDP_REW_FEET_SLIDE: {
+            const float* hist = (const float*)t.p0;
+            const float* body = (const float*)t.p1;
+            int H = t.i0, Bs = t.i1, Ba = t.i2, n = red_count(t, Bs);
+            float s = 0.0f;
+            for (int k = 0; k < n; ++k) {
+                float contact = contact_hist_max(hist, e, H, Bs, idx_at(t, pool, k)) > 1.0f ? 1.0f : 0.0f;
+                const float* bs = body + ((int64_t)e * Ba + idx2_at(t, pool, k)) * 13;
+                s += norm2(bs[7], bs[8]) * contact;
+            }
+            return s;
+        }
+        case MDP_REW_TRACK_LIN_VEL_XY_YAW_FRAME_EXP: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* c = (const float*)t.p1 + (int64_t)e * t.i1;
+            V3 v = quat_rotate_inverse(yaw_quat(ld4(r + 3)), ld3(r + 7));
+            float dx = c[0] - v.x, dy = c[1] - v.y;
+            return expf(-(dx * dx + dy * dy) / t.f0);
+        }
+        case MDP_REW_TRACK_ANG_VEL_Z_WORLD_EXP: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* c = (const float*)t.p1 + (int64_t)e * t.i1;
+            float d = c[2] - r[12];
+            return expf(-(d * d) / t.f0);
+        }
+        default: return 0.0f;
+    }
+}
+
+// reward_manager.py:128-157
+__global__ void k_reward(const mdp_term_t* __restrict__ terms, int T, const int32_t* __restrict__ pool, int N,
+                         float dt, float* __restrict__ reward, float* __restrict__ sums, float* __restrict__ step) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x) {
+        float total = 0.0f;
+        for (int ti = 0; ti < T; ++ti) {
+            const mdp_term_t& t = terms[ti];
+            if (t.weight == 0.0f) continue;
+            float value = reward_value(t, pool, e, N) * t.weight * dt;
+            total += value;
+            if (sums) sums[(int64_t)t.out_offset * N + e] += value;
+            if (step) step[(int64_t)e * T + t.out_offset] = value / dt;
+        }
+        reward[e] = total;
+    }
+}
+// =============================================================================================
+// Terminations
+// =============================================================================================
+MDP_DEV bool term_value(const mdp_term_t& t, const int32_t* __restrict__ pool, int e) {
+    switch (t.op) {
+        case MDP_TERM_EXTERNAL: return ((const uint8_t*)t.p0)[e] != 0;
+        case MDP_TERM_TIME_OUT: return ((const int64_t*)t.p0)[e] >= t.l0;
+        case MDP_TERM_COMMAND_RESAMPLE:
+            return (((const float*)t.p0)[e] <= t.f0) && (((const int64_t*)t.p1)[e] == (int64_t)t.i0);
+        case MDP_TERM_BAD_ORIENTATION: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            V3 g = quat_rotate_inverse(ld4(r + 3), V3{t.f0, t.f1, t.f2});
+            return fabsf(acosf(-g.z)) > t.f3;
+        }
+        case MDP_TERM_ROOT_HEIGHT_BELOW_MINIMUM:
+            return ((const float*)t.p0)[(int64_t)e * t.i0 + 2] < t.f0;
+        case MDP_TERM_JOINT_POS_OUT_OF_MANUAL_LIMIT: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            int n = red_count(t, t.i1);
+            bool up = false, lo = false;
+            for (int k = 0; k < n; ++k) {
+                float v = p[idx_at(t, pool, k)];
+                up = up || (v > t.f1);
+                lo = lo || (v < t.f0);
+            }
+            return up || lo;
+        }
+        case MDP_TERM_JOINT_VEL_OUT_OF_LIMIT: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* lim = (const float*)t.p1 + (int64_t)e * t.i1;
+            int n = red_count(t, t.i1);
+            bool any = false;
+            for (int k = 0; k < n; ++k) { int j = idx_at(t, pool, k); any = any || (fabsf(p[j]) > lim[j]); }
+            return any;
+        }
+        case MDP_TERM_JOINT_VEL_OUT_OF_MANUAL_LIMIT: {
+            const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
+            int n = red_count(t, t.i1);
+            bool any = false;
+            for (int k = 0; k < n; ++k) any = any || (fabsf(p[idx_at(t, pool, k)]) > t.f0);
+            return any;
+        }
+        case MDP_TERM_JOINT_EFFORT_OUT_OF_LIMIT: {
+            // torch.isclose(computed, applied): |a-b| <= atol + rtol*|b| (rtol 1e-5, atol 1e-8), equal infs close
+            const float* a = (const float*)t.p0 + (int64_t)e * t.i0;
+            const float* b = (const float*)t.p1 + (int64_t)e * t.i0;
+            int n = red_count(t, t.i1);
+            bool any = false;
+            for (int k = 0; k < n; ++k) {
+                int j = idx_at(t, pool, k);
+                float x = a[j], y = b[j];
+                bool close = (x == y) || (isfinite(x) && isfinite(y) && (fabsf(x - y) <= 1e-8f + 1e-5f * fabsf(y)));
+                any = any || close;
+            }
+            return any;
+        }
+        case MDP_TERM_ILLEGAL_CONTACT: {
+            const float* hist = (const float*)t.p0;
+            int H = t.i0, B = t.i1, n = red_count(t, B);
+            bool any = false;
+            for (int k = 0; k < n; ++k) any = any || (contact_hist_max(hist, e, H, B, idx_at(t, pool, k)) > t.f0);
+            return any;
+        }
+        case MDP_TERM_TERRAIN_OUT_OF_BOUNDS: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            return (fabsf(r[0]) > t.f0) || (fabsf(r[1]) > t.f1);
+        }
+        default: return false;
+    }
+}
+
+// termination_manager.py:151-174
+__global__ void k_termination(const mdp_term_t* __restrict__ terms, int T, const int32_t* __restrict__ pool, int N,
+                              uint8_t* __restrict__ term_dones, uint8_t* __restrict__ truncated,
+                              uint8_t* __restrict__ terminated, uint8_t* __restrict__ dones) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x) {
+        bool trunc = false, term = false;
+        for (int ti = 0; ti < T; ++ti) {
+            const mdp_term_t& t = terms[ti];
+            bool v = term_value(t, pool, e);
+            if (t.i3) trunc = trunc || v; else term = term || v;
+            if (term_dones) term_dones[(int64_t)t.out_offset * N + e] = v ? 1 : 0;
+        }
+        if (truncated) truncated[e] = trunc ? 1 : 0;
+        if (terminated) terminated[e] = term ? 1 : 0;
+        if (dones) dones[e] = (trunc || term) ? 1 : 0;
+    }
+}
+
+// ---- single-term evaluation: the term travels as a kernel argument (no allocation, no sync) ----
+__global__ void k_obs_single(mdp_term_t t, const int32_t* __restrict__ pool, int N, float* __restrict__ out, int ld,
+                             uint64_t seed, uint64_t epoch) {
+    int64_t total = (int64_t)N * t.dim;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int e = (int)(i / t.dim);
+        int k = (int)(i - (int64_t)e * t.dim);
+        float v = obs_value(t, pool, e, k);
+        out[(int64_t)e * ld + k] = obs_post(t, v, e, k, seed, epoch, 0x53494e47u, (uint64_t)i);
+    }
+}
+__global__ void k_reward_single(mdp_term_t t, const int32_t* __restrict__ pool, int N, float* __restrict__ out) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x)
+        out[e] = reward_value(t, pool, e, N);
+}
+__global__ void k_term_single(mdp_term_t t, const int32_t* __restrict__ pool, int N, uint8_t* __restrict__ out) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < N; e += gridDim.x * blockDim.x)
+        out[e] = term_value(t, pool, e) ? 1 : 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// Host API
+// =============================================================================================
+extern "C" int mdp_program_create(int kind, int device, int num_envs, const mdp_term_t* terms, int num_terms,
+                                  const int32_t* index_pool, int index_pool_len, uint64_t seed,
+                                  mdp_program_t** out) {
+    MDP_REQUIRE(out, "null out pointer");
+    MDP_REQUIRE(kind >= MDP_PROG_OBS && kind <= MDP_PROG_TERMINATION, "unknown program kind %d", kind);
+    MDP_REQUIRE(num_envs >= 0 && num_terms >= 0, "negative size");
+    MDP_REQUIRE(num_terms == 0 || terms, "null terms");
+    MDP_CHECK_HIP(hipSetDevice(device));
+    mdp_program* p = new mdp_program();
+    p->kind = kind;
+    p->device = device;
+    p->num_envs = num_envs;
+    p->num_terms = num_terms;
+    p->h_terms.assign(terms, terms + num_terms);
+    // validate + derived tables
+    std::vector<int16_t> col2term;
+    std::vector<RayAux> aux;
+    const int nops = kind == MDP_PROG_OBS ? MDP_OBS_NUM_OPS : (kind == MDP_PROG_REWARD ? MDP_REW_NUM_OPS : MDP_TERM_NUM_OPS);
+    for (int i = 0; i < num_terms; ++i) {
+        mdp_term_t& t = p->h_terms[i];
+        if (t.op < 0 || t.op >= nops) { delete p; return fail(MDP_ERR_INVALID, "term %d: unknown opcode %d", i, t.op); }
+        if (t.n_idx > 0 && (t.idx_offset < 0 || t.idx_offset + t.n_idx > index_pool_len)) {
+            delete p;
+            return fail(MDP_ERR_INVALID, "term %d: index list out of the pool", i);
+        }
+        if (t.n_idx2 > 0 && (t.idx2_offset < 0 || t.idx2_offset + t.n_idx2 > index_pool_len)) {
+            delete p;
+            return fail(MDP_ERR_INVALID, "term %d: second index list out of the pool", i);
+        }
+        if (kind == MDP_PROG_OBS) {
+            if (t.dim <= 0 || t.out_offset < 0) { delete p; return fail(MDP_ERR_INVALID, "term %d: bad dim/offset", i); }
+            if (t.out_offset + t.dim > 32767 * 4) { delete p; return fail(MDP_ERR_INVALID, "observation too wide"); }
+            if ((int)col2term.size() < t.out_offset + t.dim) col2term.resize(t.out_offset + t.dim, -1);
+            for (int k = 0; k < t.dim; ++k) col2term[t.out_offset + k] = (int16_t)i;
+            if (t.noise_kind == 1 || t.noise_kind == 2) p->uses_rng |= (t.noise_u == nullptr);
+            if (t.op == MDP_OBS_HEIGHT_SCAN_CAST) {
+                const mdp_raycaster_desc_t* d = (const mdp_raycaster_desc_t*)t.p4;
+                if (!d || !d->mesh || !d->root_pose || !d->ray_starts_local || !d->ray_dirs_local || !d->pos_w ||
+                    !d->quat_w || !d->ray_hits_w || d->num_rays != t.dim || d->ld_pose < 7) {
+                    delete p;
+                    return fail(MDP_ERR_INVALID, "term %d: invalid ray-caster binding", i);
+                }
+                RayAux a;
+                a.mesh = d->mesh->view;
+                a.d = *d;
+                a.d.mesh = nullptr;
+                aux.push_back(a);
+                p->has_cast = 1;
+            }
+        } else {
+            if (t.out_offset < 0 || t.out_offset >= num_terms) {
+                delete p;
+                return fail(MDP_ERR_INVALID, "term %d: slot %d out of range", i, t.out_offset);
+            }
+        }
+    }
+    for (size_t c = 0; c < col2term.size(); ++c)
+        if (col2term[c] < 0) { delete p; return fail(MDP_ERR_INVALID, "observation column %zu not covered by a term", c); }
+    p->total_cols = (int)col2term.size();
+    // upload
+    auto dmalloc = [](void** d, size_t n) { return hipMalloc(d, n ? n : 16); };
+    if (!aux.empty()) {
+        MDP_CHECK_HIP(dmalloc((void**)&p->d_aux, aux.size() * sizeof(RayAux)));
+        MDP_CHECK_HIP(hipMemcpy(p->d_aux, aux.data(), aux.size() * sizeof(RayAux), hipMemcpyHostToDevice));
+        size_t ai = 0;
+        for (auto& t : p->h_terms)
+            if (kind == MDP_PROG_OBS && t.op == MDP_OBS_HEIGHT_SCAN_CAST) t.p4 = p->d_aux + ai++;
+    }
+    MDP_CHECK_HIP(dmalloc((void**)&p->d_terms, sizeof(mdp_term_t) * (size_t)num_terms));
+    if (num_terms)
+        MDP_CHECK_HIP(hipMemcpy(p->d_terms, p->h_terms.data(), sizeof(mdp_term_t) * (size_t)num_terms,
+                                hipMemcpyHostToDevice));
+    MDP_CHECK_HIP(dmalloc((void**)&p->d_pool, sizeof(int32_t) * (size_t)index_pool_len));
+    if (index_pool_len)
+        MDP_CHECK_HIP(hipMemcpy(p->d_pool, index_pool, sizeof(int32_t) * (size_t)index_pool_len, hipMemcpyHostToDevice));
+    if (!col2term.empty()) {
+        MDP_CHECK_HIP(dmalloc((void**)&p->d_col2term, sizeof(int16_t) * col2term.size()));
+        MDP_CHECK_HIP(hipMemcpy(p->d_col2term, col2term.data(), sizeof(int16_t) * col2term.size(), hipMemcpyHostToDevice));
+    }
+    uint64_t rng[4] = {seed, 0, 0, 0};
+    MDP_CHECK_HIP(dmalloc((void**)&p->d_rng, sizeof(rng)));
+    MDP_CHECK_HIP(hipMemcpy(p->d_rng, rng, sizeof(rng), hipMemcpyHostToDevice));
+    *out = p;
+    return MDP_OK;
+}
+
+extern "C" int mdp_program_destroy(mdp_program_t* p) {
+    if (!p) return MDP_OK;
+    (void)hipSetDevice(p->device);
+    (void)hipFree(p->d_terms);
+    (void)hipFree(p->d_pool);
+    (void)hipFree(p->d_aux);
+    (void)hipFree(p->d_col2term);
+    (void)hipFree(p->d_rng);
+    delete p;
+    return MDP_OK;
+}
+
+extern "C" int mdp_obs_compute(mdp_program_t* p, float* obs, int ld_obs, void* stream) {
+    MDP_REQUIRE(p && p->kind == MDP_PROG_OBS, "not an observation program");
+    MDP_REQUIRE(obs && ld_obs >= p->total_cols, "obs buffer too narrow (%d < %d)", ld_obs, p->total_cols);
+    if (p->num_envs == 0 || p->total_cols == 0) return MDP_OK;
+    int O = p->total_cols;
+    int epb = O >= 256 ? 1 : 256 / O;
+    int slot_w = O >= 256 ? 256 : O;
+    int threads = ((epb * slot_w + 63) / 64) * 64;
+    int64_t blocks = ((int64_t)p->num_envs + epb - 1) / epb;
+    hipLaunchKernelGGL(k_obs, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0, as_stream(stream), p->d_terms,
+                       p->num_terms, p->d_pool, p->d_col2term, O, p->num_envs, epb, slot_w, obs, ld_obs, p->d_rng,
+                       p->uses_rng, p->has_cast);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_reward_compute(mdp_program_t* p, float dt, float* reward_buf, float* episode_sums,
+                                  float* step_reward, void* stream) {
+    MDP_REQUIRE(p && p->kind == MDP_PROG_REWARD, "not a reward program");
+    MDP_REQUIRE(reward_buf, "null reward buffer");
+    if (p->num_envs == 0) return MDP_OK;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_reward, dim3(grid_for(p->num_envs, 64, 1 << 20)), dim3(64), 0, s, p->d_terms,
+                       p->num_terms, p->d_pool, p->num_envs, dt, reward_buf, episode_sums, step_reward);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_termination_compute(mdp_program_t* p, uint8_t* term_dones, uint8_t* truncated,
+                                       uint8_t* terminated, uint8_t* dones, void* stream) {
+    MDP_REQUIRE(p && p->kind == MDP_PROG_TERMINATION, "not a termination program");
+    if (p->num_envs == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_termination, dim3(grid_for(p->num_envs, 64, 1 << 20)), dim3(64), 0, as_stream(stream),
+                       p->d_terms, p->num_terms, p->d_pool, p->num_envs, term_dones, truncated, terminated, dones);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_obs_postprocess(const mdp_term_t* term, int num_envs, float* data, int ld, uint64_t seed,
+                                   uint64_t offset, void* stream) {
+    MDP_REQUIRE(term && data, "null pointer");
+    MDP_REQUIRE(term->dim > 0 && ld >= term->dim, "bad dim/ld");
+    if (num_envs == 0) return MDP_OK;
+    int64_t total = (int64_t)num_envs * term->dim;
+    hipLaunchKernelGGL(k_obs_post, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *term, num_envs, data,
+                       ld, seed, offset);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_term_eval(int kind, const mdp_term_t* term, const int32_t* index_pool, int num_envs, void* out,
+                             int ld_out, uint64_t seed, uint64_t epoch, void* stream) {
+    MDP_REQUIRE(term && out, "null pointer");
+    MDP_REQUIRE(kind >= MDP_PROG_OBS && kind <= MDP_PROG_TERMINATION, "unknown program kind %d", kind);
+    MDP_REQUIRE(term->n_idx <= 0 || index_pool, "index list without a pool");
+    if (num_envs == 0) return MDP_OK;
+    hipStream_t s = as_stream(stream);
+    if (kind == MDP_PROG_OBS) {
+        MDP_REQUIRE(term->op >= 0 && term->op < MDP_OBS_NUM_OPS && term->op != MDP_OBS_HEIGHT_SCAN_CAST,
+                    "opcode %d cannot be evaluated stand-alone", term->op);
+        MDP_REQUIRE(term->dim > 0 && ld_out >= term->dim, "bad dim/ld");
+        int64_t total = (int64_t)num_envs * term->dim;
+        hipLaunchKernelGGL(k_obs_single, dim3(grid_for(total, 256)), dim3(256), 0, s, *term, index_pool, num_envs,
+                           (float*)out, ld_out, seed, epoch);
+    } else if (kind == MDP_PROG_REWARD) {
+        MDP_REQUIRE(term->op >= 0 && term->op < MDP_REW_NUM_OPS, "unknown reward opcode %d", term->op);
+        hipLaunchKernelGGL(k_reward_single, dim3(grid_for(num_envs, 64, 1 << 20)), dim3(64), 0, s, *term, index_pool,
+                           num_envs, (float*)out);
+    } else {
+        MDP_REQUIRE(term->op >= 0 && term->op < MDP_TERM_NUM_OPS, "unknown termination opcode %d", term->op);
+        hipLaunchKernelGGL(k_term_single, dim3(grid_for(num_envs, 64, 1 << 20)), dim3(64), 0, s, *term, index_pool,
+                           num_envs, (uint8_t*)out);
+    }
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}

@@ -1,0 +1,421 @@
+// Mesh acceleration-structure builder (host) and ray-casting kernels.
+// Reference: LAB/utils/warp/ops.py:24-145, LAB/utils/warp/kernels.py:13-75,
+//            LAB/sensors/ray_caster/ray_caster.py:220-260, LAB/sensors/sensor_base.py:284-293
+#include "mdp_device.hpp"
+#include "mdp_host.hpp"
+#include "raycast_device.hpp"
+#include "mesh_handle.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+using namespace mdp;
+
+// =============================================================================================
+// Host builders
+// =============================================================================================
+namespace {
+
+struct Tri2 {
+    float ax, ay, bx, by, cx, cy;
+};
+
+// conservative 2-D triangle / axis-aligned rectangle overlap (separating axis test, padded)
+bool tri_rect_overlap(const Tri2& t, float x0, float y0, float x1, float y1, float pad) {
+    x0 -= pad; y0 -= pad; x1 += pad; y1 += pad;
+    float tminx = std::min(t.ax, std::min(t.bx, t.cx)), tmaxx = std::max(t.ax, std::max(t.bx, t.cx));
+    float tminy = std::min(t.ay, std::min(t.by, t.cy)), tmaxy = std::max(t.ay, std::max(t.by, t.cy));
+    if (tmaxx < x0 || tminx > x1 || tmaxy < y0 || tminy > y1) return false;
+    // triangle edge normals
+    const float px[3] = {t.ax, t.bx, t.cx}, py[3] = {t.ay, t.by, t.cy};
+    const float rx[4] = {x0, x1, x1, x0}, ry[4] = {y0, y0, y1, y1};
+    for (int i = 0; i < 3; ++i) {
+        int j = (i + 1) % 3, k = (i + 2) % 3;
+        double nx = -(double)(py[j] - py[i]), ny = (double)(px[j] - px[i]);
+        double len = std::sqrt(nx * nx + ny * ny);
+        if (len == 0.0) continue;  // degenerate edge: bbox test above already covers it
+        // orient the normal away from the opposite vertex
+        double side = nx * ((double)px[k] - px[i]) + ny * ((double)py[k] - py[i]);
+        if (side > 0) { nx = -nx; ny = -ny; }
+        // rectangle entirely on the outside of this edge?
+        double dmin = 1e300;
+        for (int c = 0; c < 4; ++c) {
+            double d = nx * ((double)rx[c] - px[i]) + ny * ((double)ry[c] - py[i]);
+            dmin = std::min(dmin, d);
+        }
+        if (dmin > 1e-7 * len * (std::fabs((double)x0) + std::fabs((double)y0) + 1.0)) return false;
+    }
+    return true;
+}
+
+inline uint32_t expand_bits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+struct BvhBuilder {
+    const float* tv;  // 9 floats per tri
+    std::vector<uint32_t> codes;
+    std::vector<int32_t> order;  // sorted triangle ids
+    std::vector<float> nodes;    // 8 floats per node
+    int leaf_size = 4;
+
+    void bounds(int lo, int hi, float* mn, float* mx) const {
+        for (int a = 0; a < 3; ++a) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -mn[a]; }
+        for (int i = lo; i < hi; ++i) {
+            const float* t = tv + 9 * (int64_t)order[i];
+            for (int v = 0; v < 3; ++v)
+                for (int a = 0; a < 3; ++a) {
+                    mn[a] = std::min(mn[a], t[3 * v + a]);
+                    mx[a] = std::max(mx[a], t[3 * v + a]);
+                }
+        }
+    }
+    int find_split(int lo, int hi) const {
+        uint32_t first = codes[lo], last = codes[hi - 1];
+        if (first == last) return (lo + hi) / 2;
+        int common = __builtin_clz(first ^ last);
+        int split = lo;
+        int step = hi - 1 - lo;
+        do {
+            step = (step + 1) >> 1;
+            int ns = split + step;
+            if (ns < hi - 1) {
+                if (__builtin_clz(first ^ codes[ns]) > common) split = ns;
+            }
+        } while (step > 1);
+        return split + 1;
+    }
+    // iterative build with an explicit work list; children of a node are allocated adjacently
+    void build(int n) {
+        nodes.clear();
+        nodes.resize(8);
+        struct Item { int node, lo, hi, depth; };
+        std::vector<Item> work;
+        work.push_back({0, 0, n, 0});
+        while (!work.empty()) {
+            Item it = work.back();
+            work.pop_back();
+            float mn[3], mx[3];
+            bounds(it.lo, it.hi, mn, mx);
+            float* nd = nodes.data() + 8 * (int64_t)it.node;
+            nd[0] = mn[0]; nd[1] = mn[1]; nd[2] = mn[2];
+            nd[4] = mx[0]; nd[5] = mx[1]; nd[6] = mx[2];
+            int count = it.hi - it.lo;
+            if (count <= leaf_size || it.depth >= 56) {
+                reinterpret_cast<int32_t*>(nd)[3] = it.lo;
+                reinterpret_cast<int32_t*>(nd)[7] = count;
+                continue;
+            }
+            int mid = find_split(it.lo, it.hi);
+            int child = (int)(nodes.size() / 8);
+            nodes.resize(nodes.size() + 16);
+            nd = nodes.data() + 8 * (int64_t)it.node;  // resize may move
+            reinterpret_cast<int32_t*>(nd)[3] = child;
+            reinterpret_cast<int32_t*>(nd)[7] = 0;
+            work.push_back({child, it.lo, mid, it.depth + 1});
+            work.push_back({child + 1, mid, it.hi, it.depth + 1});
+        }
+    }
+};
+
+template <class T>
+int upload(const std::vector<T>& h, T** d, int64_t* bytes) {
+    size_t n = h.size() * sizeof(T);
+    if (n == 0) n = sizeof(T);
+    MDP_CHECK_HIP(hipMalloc((void**)d, n));
+    if (!h.empty()) MDP_CHECK_HIP(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *bytes += (int64_t)n;
+    return MDP_OK;
+}
+
+}  // namespace
+
+extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_t* indices, int num_tris,
+                               int device, int accel, mdp_mesh_t** out) {
+    MDP_REQUIRE(points && indices && out, "null pointer");
+    MDP_REQUIRE(num_points > 0 && num_tris > 0, "empty mesh (%d points, %d triangles)", num_points, num_tris);
+    MDP_REQUIRE(accel >= 0 && accel <= 2, "accel must be 0 (auto), 1 (grid) or 2 (bvh)");
+    for (int64_t i = 0; i < (int64_t)num_tris * 3; ++i)
+        MDP_REQUIRE(indices[i] >= 0 && indices[i] < num_points, "triangle index %d out of range at %lld",
+                    indices[i], (long long)i);
+    MDP_CHECK_HIP(hipSetDevice(device));
+    mdp_mesh* m = new mdp_mesh();
+    m->device = device;
+    m->num_tris = num_tris;
+    // ---- triangle soup
+    std::vector<float> tv((size_t)num_tris * 9);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int f = 0; f < num_tris; ++f)
+        for (int v = 0; v < 3; ++v) {
+            const float* p = points + 3 * (int64_t)indices[3 * (int64_t)f + v];
+            for (int a = 0; a < 3; ++a) {
+                tv[9 * (size_t)f + 3 * v + a] = p[a];
+                mn[a] = std::min(mn[a], p[a]);
+                mx[a] = std::max(mx[a], p[a]);
+            }
+        }
+    // ---- uniform xy grid
+    double ex = (double)mx[0] - mn[0], ey = (double)mx[1] - mn[1];
+    double area = std::max(ex, 1e-6) * std::max(ey, 1e-6);
+    double cell = std::sqrt(2.0 * area / (double)num_tris);
+    const double max_cells = 8.0e6;
+    if ((ex / cell + 2) * (ey / cell + 2) > max_cells) cell = std::sqrt((ex + 1e-6) * (ey + 1e-6) / (max_cells * 0.9));
+    if (!(cell > 0)) cell = 1.0;
+    // half-cell offset keeps lattice-aligned height-field edges away from cell borders
+    float gx0 = (float)(mn[0] - 0.5 * cell), gy0 = (float)(mn[1] - 0.5 * cell);
+    int ncx = (int)std::floor((mx[0] - gx0) / cell) + 1, ncy = (int)std::floor((mx[1] - gy0) / cell) + 1;
+    ncx = std::max(ncx, 1);
+    ncy = std::max(ncy, 1);
+    float cellf = (float)cell;
+    float pad = 1e-3f * cellf + 1e-6f;
+    std::vector<int32_t> counts((size_t)ncx * ncy + 1, 0);
+    auto cell_range = [&](const float* t, int& x0, int& x1, int& y0, int& y1) {
+        float tminx = std::min(t[0], std::min(t[3], t[6])) - pad, tmaxx = std::max(t[0], std::max(t[3], t[6])) + pad;
+        float tminy = std::min(t[1], std::min(t[4], t[7])) - pad, tmaxy = std::max(t[1], std::max(t[4], t[7])) + pad;
+        x0 = std::max(0, (int)std::floor((tminx - gx0) / cellf));
+        x1 = std::min(ncx - 1, (int)std::floor((tmaxx - gx0) / cellf));
+        y0 = std::max(0, (int)std::floor((tminy - gy0) / cellf));
+        y1 = std::min(ncy - 1, (int)std::floor((tmaxy - gy0) / cellf));
+    };
+    auto overlaps = [&](const float* t, int cx, int cy) {
+        Tri2 t2{t[0], t[1], t[3], t[4], t[6], t[7]};
+        float x0 = gx0 + cellf * (float)cx, y0 = gy0 + cellf * (float)cy;
+        return tri_rect_overlap(t2, x0, y0, x0 + cellf, y0 + cellf, pad);
+    };
+    for (int pass = 0; pass < 2; ++pass) {
+        std::vector<int32_t> cursor;
+        if (pass == 1) {
+            // exclusive scan
+            int32_t run = 0;
+            for (size_t c = 0; c < counts.size(); ++c) { int32_t v = counts[c]; counts[c] = run; run += v; }
+            cursor.assign(counts.begin(), counts.end() - 1);
+            m->h_cell_tris.resize((size_t)counts.back());
+        }
+        for (int f = 0; f < num_tris; ++f) {
+            const float* t = tv.data() + 9 * (size_t)f;
+            int x0, x1, y0, y1;
+            cell_range(t, x0, x1, y0, y1);
+            for (int cy = y0; cy <= y1; ++cy)
+                for (int cx = x0; cx <= x1; ++cx) {
+                    if (!overlaps(t, cx, cy)) continue;
+                    size_t c = (size_t)cy * ncx + cx;
+                    if (pass == 0) counts[c]++;
+                    else m->h_cell_tris[(size_t)cursor[c]++] = f;  // ascending face id within a cell
+                }
+        }
+    }
+    // ---- BVH
+    BvhBuilder bb;
+    bb.tv = tv.data();
+    bb.codes.resize(num_tris);
+    bb.order.resize(num_tris);
+    std::iota(bb.order.begin(), bb.order.end(), 0);
+    {
+        double sx = 1.0 / std::max((double)mx[0] - mn[0], 1e-12), sy = 1.0 / std::max((double)mx[1] - mn[1], 1e-12),
+               sz = 1.0 / std::max((double)mx[2] - mn[2], 1e-12);
+        std::vector<uint32_t> code_by_tri(num_tris);
+        for (int f = 0; f < num_tris; ++f) {
+            const float* t = tv.data() + 9 * (size_t)f;
+            double cxv = ((double)t[0] + t[3] + t[6]) / 3.0, cyv = ((double)t[1] + t[4] + t[7]) / 3.0,
+                   czv = ((double)t[2] + t[5] + t[8]) / 3.0;
+            auto q = [](double v) { return (uint32_t)std::min(std::max(v * 1024.0, 0.0), 1023.0); };
+            code_by_tri[f] = (expand_bits(q((cxv - mn[0]) * sx)) << 2) | (expand_bits(q((cyv - mn[1]) * sy)) << 1) |
+                             expand_bits(q((czv - mn[2]) * sz));
+        }
+        std::stable_sort(bb.order.begin(), bb.order.end(),
+                         [&](int32_t a, int32_t b) { return code_by_tri[a] < code_by_tri[b]; });
+        for (int i = 0; i < num_tris; ++i) bb.codes[i] = code_by_tri[bb.order[i]];
+    }
+    bb.build(num_tris);
+
+    // ---- upload
+    int64_t bytes = 0;
+    int rc;
+    float* d_tv = nullptr; int32_t* d_cs = nullptr; int32_t* d_ct = nullptr; float* d_nodes = nullptr; int32_t* d_bt = nullptr;
+    if ((rc = upload(tv, &d_tv, &bytes)) || (rc = upload(counts, &d_cs, &bytes)) ||
+        (rc = upload(m->h_cell_tris, &d_ct, &bytes)) || (rc = upload(bb.nodes, &d_nodes, &bytes)) ||
+        (rc = upload(bb.order, &d_bt, &bytes))) {
+        delete m;
+        return rc;
+    }
+    m->num_cell_refs = (int64_t)m->h_cell_tris.size();
+    m->h_cell_tris.clear();
+    m->h_cell_tris.shrink_to_fit();
+    m->device_bytes = bytes;
+    mdp_mesh_view_t& v = m->view;
+    v.tri_verts = d_tv;
+    v.num_tris = num_tris;
+    v.cell_start = d_cs;
+    v.cell_tris = d_ct;
+    v.gx0 = gx0; v.gy0 = gy0; v.cell = cellf; v.inv_cell = 1.0f / cellf;
+    v.ncx = ncx; v.ncy = ncy;
+    v.zmin = mn[2]; v.zmax = mx[2];
+    v.bvh_nodes = d_nodes;
+    v.bvh_tris = d_bt;
+    v.num_nodes = (int32_t)(bb.nodes.size() / 8);
+    // auto: terrain-like meshes (few refs per cell on average, bounded z-extent per footprint) use the
+    // grid; anything whose cell lists blow up (many overlapping layers / huge triangles) uses the BVH
+    double refs_per_cell = (double)m->num_cell_refs / ((double)ncx * ncy);
+    double refs_per_tri = (double)m->num_cell_refs / (double)num_tris;
+    int chosen = accel;
+    if (chosen == 0) chosen = (refs_per_cell <= 64.0 && refs_per_tri <= 64.0) ? 1 : 2;
+    v.accel = chosen;
+    *out = m;
+    return MDP_OK;
+}
+
+extern "C" int mdp_mesh_destroy(mdp_mesh_t* mesh) {
+    if (!mesh) return MDP_OK;
+    (void)hipSetDevice(mesh->device);
+    (void)hipFree((void*)mesh->view.tri_verts);
+    (void)hipFree((void*)mesh->view.cell_start);
+    (void)hipFree((void*)mesh->view.cell_tris);
+    (void)hipFree((void*)mesh->view.bvh_nodes);
+    (void)hipFree((void*)mesh->view.bvh_tris);
+    delete mesh;
+    return MDP_OK;
+}
+
+extern "C" int mdp_mesh_info(const mdp_mesh_t* mesh, int64_t* num_tris, int64_t* num_cells, int64_t* num_cell_refs,
+                             int64_t* num_bvh_nodes, int64_t* device_bytes, int* accel) {
+    MDP_REQUIRE(mesh, "null mesh");
+    if (num_tris) *num_tris = mesh->num_tris;
+    if (num_cells) *num_cells = (int64_t)mesh->view.ncx * mesh->view.ncy;
+    if (num_cell_refs) *num_cell_refs = mesh->num_cell_refs;
+    if (num_bvh_nodes) *num_bvh_nodes = mesh->view.num_nodes;
+    if (device_bytes) *device_bytes = mesh->device_bytes;
+    if (accel) *accel = mesh->view.accel;
+    return MDP_OK;
+}
+
+// =============================================================================================
+// Kernels
+// =============================================================================================
+namespace {
+
+// ops.py:61-127 + kernels.py:55-75: one thread per ray
+__global__ void k_raycast(mdp_mesh_view_t mesh, int64_t num_rays, const float* __restrict__ starts,
+                          const float* __restrict__ dirs, float max_dist, float* __restrict__ hits,
+                          float* __restrict__ dist, float* __restrict__ normal, int32_t* __restrict__ face,
+                          int accel) {
+    const float inf = __builtin_inff();
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < num_rays;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float ox = starts[3 * i], oy = starts[3 * i + 1], oz = starts[3 * i + 2];
+        float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
+        mdp_ray_t r = mdp_rc_make_ray(ox, oy, oz, dx, dy, dz);
+        mdp_hit_t h = mdp_rc_query(&mesh, &r, max_dist, accel);
+        if (h.face >= 0) {
+            // kernels.py:69: ray_hits = start + t * dir
+            hits[3 * i] = ox + h.t * dx;
+            hits[3 * i + 1] = oy + h.t * dy;
+            hits[3 * i + 2] = oz + h.t * dz;
+            if (dist) dist[i] = h.t;
+            if (normal) {
+                float nx, ny, nz;
+                mdp_rc_normal(mesh.tri_verts + 9 * (int64_t)h.face, &nx, &ny, &nz);
+                normal[3 * i] = nx; normal[3 * i + 1] = ny; normal[3 * i + 2] = nz;
+            }
+            if (face) face[i] = h.face;
+        } else {
+            hits[3 * i] = inf; hits[3 * i + 1] = inf; hits[3 * i + 2] = inf;
+            if (dist) dist[i] = inf;
+            if (normal) { normal[3 * i] = inf; normal[3 * i + 1] = inf; normal[3 * i + 2] = inf; }
+            if (face) face[i] = -1;
+        }
+    }
+}
+
+// ray_caster.py:220-260 with the lazy-update bookkeeping of sensor_base.py:284-293.
+// A block owns whole environments (slot_w threads each) so the outdated flag can be read by every
+// ray thread and cleared by the env's first thread after a block barrier.
+__global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w,
+                                   const float* __restrict__ pose, int ld_pose, const float* __restrict__ drift,
+                                   const float* __restrict__ starts_l, const float* __restrict__ dirs_l,
+                                   int yaw_only, float max_dist, float* __restrict__ pos_w,
+                                   float* __restrict__ quat_w, float* __restrict__ hits,
+                                   const float* __restrict__ ts, float* __restrict__ ts_last,
+                                   uint8_t* __restrict__ outdated) {
+    const float inf = __builtin_inff();
+    int le = threadIdx.x / slot_w;
+    int lr = threadIdx.x - le * slot_w;
+    for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
+        int e = base + le;
+        bool active = le < epb && e < N;
+        bool od = active && (outdated ? outdated[e] != 0 : true);
+        __syncthreads();
+        if (od) {
+            const float* p = pose + (int64_t)e * ld_pose;
+            V3 pos = ld3(p);
+            if (drift) { pos.x += drift[3 * e]; pos.y += drift[3 * e + 1]; pos.z += drift[3 * e + 2]; }
+            Q4 q = ld4(p + 3);
+            Q4 qr = yaw_only ? yaw_quat(q) : q;
+            for (int r = lr; r < R; r += slot_w) {
+                V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
+                s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
+                V3 d = ld3(dirs_l + 3 * r);
+                if (!yaw_only) d = quat_apply(q, d);
+                mdp_ray_t ray = mdp_rc_make_ray(s.x, s.y, s.z, d.x, d.y, d.z);
+                mdp_hit_t h = mdp_rc_query(&mesh, &ray, max_dist, mesh.accel);
+                float* o = hits + ((int64_t)e * R + r) * 3;
+                if (h.face >= 0) {
+                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = s.z + h.t * d.z;
+                } else {
+                    o[0] = inf; o[1] = inf; o[2] = inf;
+                }
+            }
+            if (lr == 0) {
+                st3(pos_w + 3 * (int64_t)e, pos);
+                st4(quat_w + 4 * (int64_t)e, q);
+                if (ts_last) ts_last[e] = ts[e];
+                if (outdated) outdated[e] = 0;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mdp_raycast(const mdp_mesh_t* mesh, int64_t num_rays, const float* ray_starts, const float* ray_dirs,
+                           float max_dist, float* ray_hits, float* ray_dist, float* ray_normal,
+                           int32_t* ray_face_id, int accel, void* stream) {
+    MDP_REQUIRE(mesh && ray_starts && ray_dirs && ray_hits, "null pointer");
+    MDP_REQUIRE(accel >= 0 && accel <= 3, "bad accel");
+    if (num_rays == 0) return MDP_OK;
+    int a = accel == 0 ? mesh->view.accel : (accel == 3 ? 0 : accel);  // 3 = brute force (tests)
+    hipLaunchKernelGGL(k_raycast, dim3(grid_for(num_rays, 128, 1 << 20)), dim3(128), 0, as_stream(stream),
+                       mesh->view, num_rays, ray_starts, ray_dirs, max_dist, ray_hits, ray_dist, ray_normal,
+                       ray_face_id, a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int num_rays, const float* root_pose,
+                                    int ld_pose, const float* drift, const float* ray_starts_local,
+                                    const float* ray_dirs_local, int attach_yaw_only, float max_dist, float* pos_w,
+                                    float* quat_w, float* ray_hits_w, const float* timestamp,
+                                    float* timestamp_last_update, uint8_t* is_outdated, void* stream) {
+    MDP_REQUIRE(mesh && root_pose && ray_starts_local && ray_dirs_local && pos_w && quat_w && ray_hits_w,
+                "null pointer");
+    MDP_REQUIRE(ld_pose >= 7, "root_pose must be (N,>=7)");
+    MDP_REQUIRE((timestamp_last_update == nullptr) || timestamp, "timestamp required with timestamp_last_update");
+    if (num_envs == 0 || num_rays == 0) return MDP_OK;
+    int epb = num_rays >= 256 ? 1 : 256 / num_rays;
+    int slot_w = num_rays >= 256 ? 256 : num_rays;
+    int threads = ((epb * slot_w + 63) / 64) * 64;
+    int64_t blocks = ((int64_t)num_envs + epb - 1) / epb;
+    hipLaunchKernelGGL(k_raycaster_update, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0, as_stream(stream),
+                       mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift, ray_starts_local,
+                       ray_dirs_local, attach_yaw_only, max_dist, pos_w, quat_w, ray_hits_w, timestamp,
+                       timestamp_last_update, is_outdated);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}

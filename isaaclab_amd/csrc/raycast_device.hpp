@@ -1,0 +1,274 @@
+// Device-side closest-hit ray / triangle-mesh query shared by raycast.hip and programs.hip.
+//
+// Reference boundary: warp's `mesh_query_ray` as called by LAB/utils/warp/kernels.py:66.  warp-lang
+// (pinned 1.8.0 in environment.yml:285) is not part of /root/reference; its ray/triangle test is the
+// published watertight algorithm of Woop, Benthin & Wald, "Watertight Ray/Triangle Intersection",
+// JCGT 2(1), 2013, restated here (double-precision fallback on zero edge functions, two-sided,
+// hits with t >= 0 and t < max_t).  Closest hit; exact ties on t are broken by the SMALLEST face id so the
+// result is independent of traversal order (grid, BVH and the brute-force oracle agree bit for bit).
+//
+// The same source text is compiled by gcc for the CPU oracle (oracle/raycast_oracle.c includes this
+// file with MDP_RC_HOST defined) so both sides evaluate the identical expression trees with
+// -ffp-contract=off.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#ifdef MDP_RC_HOST
+#define MDP_RC_FN static inline
+#else
+#include <hip/hip_runtime.h>
+#define MDP_RC_FN __device__ __forceinline__
+#endif
+
+typedef struct {
+    // triangle soup (pre-gathered): tri_verts[9*f .. 9*f+8] = a, b, c
+    const float* tri_verts;
+    int32_t num_tris;
+    // uniform xy cell grid (CSR): cell_start[ncx*ncy + 1], cell_tris[...]
+    const int32_t* cell_start;
+    const int32_t* cell_tris;
+    float gx0, gy0, cell, inv_cell;
+    int32_t ncx, ncy;
+    float zmin, zmax;  // mesh z range (slab test for DDA)
+    // BVH: nodes[i] = {lo.x, lo.y, lo.z, left_or_first, hi.x, hi.y, hi.z, count}; count > 0 => leaf
+    const float* bvh_nodes;
+    const int32_t* bvh_tris;  // leaf triangle ids
+    int32_t num_nodes;
+    int32_t accel;  // 1 grid, 2 bvh
+} mdp_mesh_view_t;
+
+typedef struct {
+    float t;
+    int32_t face;
+} mdp_hit_t;
+
+MDP_RC_FN int mdp_rc_max_dim(float ax, float ay, float az) {
+    // index of the largest component (first wins on ties, like a chain of > comparisons)
+    int k = 0;
+    float m = ax;
+    if (ay > m) { m = ay; k = 1; }
+    if (az > m) { k = 2; }
+    return k;
+}
+
+// Ray prepared once per ray (the "precompute" block of the published algorithm).
+typedef struct {
+    float ox, oy, oz;
+    float dx, dy, dz;
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+} mdp_ray_t;
+
+MDP_RC_FN float mdp_rc_comp(float x, float y, float z, int k) { return k == 0 ? x : (k == 1 ? y : z); }
+
+MDP_RC_FN mdp_ray_t mdp_rc_make_ray(float ox, float oy, float oz, float dx, float dy, float dz) {
+    mdp_ray_t r;
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz;
+    int kz = mdp_rc_max_dim(fabsf(dx), fabsf(dy), fabsf(dz));
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    float dkz = mdp_rc_comp(dx, dy, dz, kz);
+    if (dkz < 0.0f) { int tmp = kx; kx = ky; ky = tmp; }
+    r.kx = kx; r.ky = ky; r.kz = kz;
+    r.Sx = mdp_rc_comp(dx, dy, dz, kx) / dkz;
+    r.Sy = mdp_rc_comp(dx, dy, dz, ky) / dkz;
+    r.Sz = 1.0f / dkz;
+    return r;
+}
+
+// returns 1 on hit and writes t (distance along the ray in units of |dir|), u, v barycentrics, det sign
+MDP_RC_FN int mdp_rc_intersect(const mdp_ray_t* r, const float* tv, float* t_out, float* u_out, float* v_out) {
+    float Ax3 = tv[0] - r->ox, Ay3 = tv[1] - r->oy, Az3 = tv[2] - r->oz;
+    float Bx3 = tv[3] - r->ox, By3 = tv[4] - r->oy, Bz3 = tv[5] - r->oz;
+    float Cx3 = tv[6] - r->ox, Cy3 = tv[7] - r->oy, Cz3 = tv[8] - r->oz;
+    float Akz = mdp_rc_comp(Ax3, Ay3, Az3, r->kz), Bkz = mdp_rc_comp(Bx3, By3, Bz3, r->kz),
+          Ckz = mdp_rc_comp(Cx3, Cy3, Cz3, r->kz);
+    float Ax = mdp_rc_comp(Ax3, Ay3, Az3, r->kx) - r->Sx * Akz;
+    float Ay = mdp_rc_comp(Ax3, Ay3, Az3, r->ky) - r->Sy * Akz;
+    float Bx = mdp_rc_comp(Bx3, By3, Bz3, r->kx) - r->Sx * Bkz;
+    float By = mdp_rc_comp(Bx3, By3, Bz3, r->ky) - r->Sy * Bkz;
+    float Cx = mdp_rc_comp(Cx3, Cy3, Cz3, r->kx) - r->Sx * Ckz;
+    float Cy = mdp_rc_comp(Cx3, Cy3, Cz3, r->ky) - r->Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
+    float det = (U + V) + W;
+    if (det == 0.0f) return 0;
+    float Az = r->Sz * Akz, Bz = r->Sz * Bkz, Cz = r->Sz * Ckz;
+    float T = (U * Az + V * Bz) + W * Cz;
+    // sign(T) must equal sign(det) (t >= 0)
+    if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) return 0;
+    float rcp = 1.0f / det;
+    *u_out = U * rcp;
+    *v_out = V * rcp;
+    *t_out = T * rcp;
+    return 1;
+}
+
+MDP_RC_FN void mdp_rc_consider(const mdp_ray_t* r, const float* tri_verts, int32_t f, mdp_hit_t* best) {
+    float t, u, v;
+    if (mdp_rc_intersect(r, tri_verts + 9 * (int64_t)f, &t, &u, &v)) {
+        if (t >= 0.0f && (t < best->t || (t == best->t && f < best->face && best->face >= 0))) {
+            best->t = t;
+            best->face = f;
+        }
+    }
+}
+
+// ---- brute force (oracle + tiny meshes) ------------------------------------------------------
+MDP_RC_FN mdp_hit_t mdp_rc_brute(const mdp_mesh_view_t* m, const mdp_ray_t* r, float max_t) {
+    mdp_hit_t best; best.t = max_t; best.face = -1;
+    for (int32_t f = 0; f < m->num_tris; ++f) mdp_rc_consider(r, m->tri_verts, f, &best);
+    return best;
+}
+
+// ---- uniform xy grid with conservative 2-D DDA -----------------------------------------------
+// Every triangle is registered in all cells its (slightly padded) xy bounding box touches, so a ray
+// only has to visit the cells its xy projection crosses.  Vertical rays (the height scan) touch one
+// cell.  The walk stops as soon as the best hit lies before the entry point of the next cell.
+MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, float max_t) {
+    mdp_hit_t best; best.t = max_t; best.face = -1;
+    float dx = r->dx, dy = r->dy;
+    // clip the parametric range [t0,t1] against the grid's xy extent and the mesh z slab
+    float t0 = 0.0f, t1 = max_t;
+    float lo[3] = {m->gx0, m->gy0, m->zmin};
+    float hi[3] = {m->gx0 + m->cell * (float)m->ncx, m->gy0 + m->cell * (float)m->ncy, m->zmax};
+    float o[3] = {r->ox, r->oy, r->oz};
+    float d[3] = {r->dx, r->dy, r->dz};
+    float pad = 1e-3f * m->cell + 1e-6f;
+    for (int a = 0; a < 3; ++a) {
+        float l = lo[a] - pad, h = hi[a] + pad;
+        if (d[a] == 0.0f) {
+            if (o[a] < l || o[a] > h) return best;
+        } else {
+            float inv = 1.0f / d[a];
+            float ta = (l - o[a]) * inv, tb = (h - o[a]) * inv;
+            if (ta > tb) { float tmp = ta; ta = tb; tb = tmp; }
+            // widen by a relative epsilon: the clip only prunes, exactness comes from the triangle test
+            ta -= fabsf(ta) * 1e-5f + 1e-6f;
+            tb += fabsf(tb) * 1e-5f + 1e-6f;
+            if (ta > t0) t0 = ta;
+            if (tb < t1) t1 = tb;
+        }
+    }
+    if (t0 > t1) return best;
+    // entry cell
+    float px = r->ox + t0 * dx, py = r->oy + t0 * dy;
+    int cx = (int)floorf((px - m->gx0) * m->inv_cell);
+    int cy = (int)floorf((py - m->gy0) * m->inv_cell);
+    if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
+    if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
+    int sx = dx > 0.0f ? 1 : (dx < 0.0f ? -1 : 0);
+    int sy = dy > 0.0f ? 1 : (dy < 0.0f ? -1 : 0);
+    const float BIG = 3.0e38f;
+    // Boundary parameters are recomputed from the integer cell index every step (no accumulation
+    // drift).  Triangles are registered with a padded footprint (pad = 1e-3 cell), so walking the
+    // unpadded lattice never misses one as long as the current cell is tested before stepping.
+    float tstep = BIG;
+    if (sx != 0) tstep = fabsf(m->cell / dx);
+    if (sy != 0) { float ty = fabsf(m->cell / dy); if (ty < tstep) tstep = ty; }
+    for (;;) {
+        int32_t c = cy * m->ncx + cx;
+        int32_t b = m->cell_start[c], e = m->cell_start[c + 1];
+        for (int32_t k = b; k < e; ++k) mdp_rc_consider(r, m->tri_verts, m->cell_tris[k], &best);
+        float tmx = sx != 0 ? ((m->gx0 + m->cell * (float)(cx + (sx > 0 ? 1 : 0))) - r->ox) / dx : BIG;
+        float tmy = sy != 0 ? ((m->gy0 + m->cell * (float)(cy + (sy > 0 ? 1 : 0))) - r->oy) / dy : BIG;
+        float t_exit = tmx < tmy ? tmx : tmy;
+        // a hit at t is final once every cell still ahead only holds points with parameter > t
+        float slack = fabsf(t_exit) * 1e-4f + 1e-2f * tstep;
+        if (best.face >= 0 && best.t < t_exit - slack) break;
+        if (t_exit > t1) break;
+        if (tmx < tmy) cx += sx; else cy += sy;
+        if (cx < 0 || cx >= m->ncx || cy < 0 || cy >= m->ncy) break;
+    }
+    return best;
+}
+
+// ---- BVH (binary, built on the host; stack traversal) -----------------------------------------
+MDP_RC_FN int mdp_rc_slab(const float* n, const mdp_ray_t* r, float inv_x, float inv_y, float inv_z, float tmax,
+                          float* t_near) {
+    // n = {lo.x, lo.y, lo.z, *, hi.x, hi.y, hi.z, *}; conservative (padded by relative eps)
+    float tx0 = (n[0] - r->ox) * inv_x, tx1 = (n[4] - r->ox) * inv_x;
+    float ty0 = (n[1] - r->oy) * inv_y, ty1 = (n[5] - r->oy) * inv_y;
+    float tz0 = (n[2] - r->oz) * inv_z, tz1 = (n[6] - r->oz) * inv_z;
+    float tminx = fminf(tx0, tx1), tmaxx = fmaxf(tx0, tx1);
+    float tminy = fminf(ty0, ty1), tmaxy = fmaxf(ty0, ty1);
+    float tminz = fminf(tz0, tz1), tmaxz = fmaxf(tz0, tz1);
+    float tn = fmaxf(fmaxf(tminx, tminy), fmaxf(tminz, 0.0f));
+    float tf = fminf(fminf(tmaxx, tmaxy), fminf(tmaxz, tmax));
+    tn -= fabsf(tn) * 1e-5f + 1e-6f;
+    tf += fabsf(tf) * 1e-5f + 1e-6f;
+    *t_near = tn;
+    return tn <= tf;
+}
+
+MDP_RC_FN float mdp_rc_safe_inv(float d) {
+    // direction components that are exactly 0 get a huge finite inverse so the slab test degrades
+    // to an origin-inside check without producing NaN (0 * inf)
+    if (d == 0.0f) return 1.0e30f;
+    return 1.0f / d;
+}
+
+MDP_RC_FN mdp_hit_t mdp_rc_bvh(const mdp_mesh_view_t* m, const mdp_ray_t* r, float max_t) {
+    mdp_hit_t best; best.t = max_t; best.face = -1;
+    if (m->num_nodes <= 0) return best;
+    float ix = mdp_rc_safe_inv(r->dx), iy = mdp_rc_safe_inv(r->dy), iz = mdp_rc_safe_inv(r->dz);
+    int32_t stack[48];
+    int sp = 0;
+    stack[sp++] = 0;
+    while (sp > 0) {
+        int32_t ni = stack[--sp];
+        const float* n = m->bvh_nodes + 8 * (int64_t)ni;
+        float tn;
+        // allow equal-t hits with a smaller face id: prune only strictly beyond best.t
+        if (!mdp_rc_slab(n, r, ix, iy, iz, best.t, &tn)) continue;
+        int32_t first = ((const int32_t*)n)[3];
+        int32_t count = ((const int32_t*)n)[7];
+        if (count > 0) {
+            for (int32_t k = 0; k < count; ++k) mdp_rc_consider(r, m->tri_verts, m->bvh_tris[first + k], &best);
+        } else {
+            // children are first, first+1; push the farther one first
+            const float* n0 = m->bvh_nodes + 8 * (int64_t)first;
+            const float* n1 = n0 + 8;
+            float t0n, t1n;
+            int h0 = mdp_rc_slab(n0, r, ix, iy, iz, best.t, &t0n);
+            int h1 = mdp_rc_slab(n1, r, ix, iy, iz, best.t, &t1n);
+            if (h0 && h1) {
+                if (t0n <= t1n) { stack[sp++] = first + 1; stack[sp++] = first; }
+                else { stack[sp++] = first; stack[sp++] = first + 1; }
+            } else if (h0) {
+                stack[sp++] = first;
+            } else if (h1) {
+                stack[sp++] = first + 1;
+            }
+            if (sp > 46) sp = 46;  // depth guard (builder limits depth to 40)
+        }
+    }
+    return best;
+}
+
+MDP_RC_FN mdp_hit_t mdp_rc_query(const mdp_mesh_view_t* m, const mdp_ray_t* r, float max_t, int accel) {
+    if (accel == 2) return mdp_rc_bvh(m, r, max_t);
+    if (accel == 1) return mdp_rc_grid(m, r, max_t);
+    return mdp_rc_brute(m, r, max_t);
+}
+
+// face normal: normalize(cross(b - a, c - a))
+MDP_RC_FN void mdp_rc_normal(const float* tv, float* nx, float* ny, float* nz) {
+    float abx = tv[3] - tv[0], aby = tv[4] - tv[1], abz = tv[5] - tv[2];
+    float acx = tv[6] - tv[0], acy = tv[7] - tv[1], acz = tv[8] - tv[2];
+    float x = aby * acz - abz * acy, y = abz * acx - abx * acz, z = abx * acy - aby * acx;
+    float l = sqrtf((x * x + y * y) + z * z);
+    if (l > 0.0f) { x /= l; y /= l; z /= l; }
+    *nx = x; *ny = y; *nz = z;
+}

@@ -1,0 +1,118 @@
+"""``ManagerBasedRLEnv.step`` call order over a synthetic physics feed
+(``LAB/envs/manager_based_rl_env.py:152-241``; the MdpStepHarness of SURVEY.md section 8c).
+
+The env reproduces the per-step order action -> decimation x {apply, write_data_to_sim, physics, update}
+-> terminations -> rewards -> (reset) -> commands -> observations.  Physics is a
+:class:`SyntheticPhysicsView` (direct writes or a replayed ring of frames); the reset path (events,
+curriculum) is the reference's host-synchronising path and is optional.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any
+
+import numpy as np
+import torch
+
+from ..assets import Articulation, SyntheticPhysicsView
+from ..managers import ActionManager, CommandManager, ObservationManager, RewardManager, TerminationManager
+from ..scene import InteractiveScene
+from ..sensors import ContactSensor, RayCaster
+from ..terrains import SyntheticTerrain, SyntheticTerrainCfg
+from ..utils.warp import Mesh, convert_to_warp_mesh
+
+
+class ManagerBasedRLEnv:
+    def __init__(self, cfg, device: str = "cuda:0", physics: SyntheticPhysicsView | None = None,
+                 mesh: Mesh | None = None, terrain: SyntheticTerrain | None = None, auto_reset: bool = False):
+        cfg.validate() if hasattr(cfg, "validate") else None
+        self.cfg = cfg
+        self.device = device
+        self.num_envs = cfg.scene.num_envs
+        self.auto_reset = auto_reset
+        self.extras: dict[str, Any] = {}
+        robot_cfg = cfg.scene.robot
+        nj, nb = len(robot_cfg.joint_names), len(robot_cfg.body_names)
+        self.physics = physics if physics is not None else SyntheticPhysicsView(self.num_envs, nj, nb, device)
+        # -- scene
+        env_origins = None
+        if terrain is not None:
+            env_origins = torch.tensor(terrain.env_origins, dtype=torch.float32, device=device)
+        self.scene = InteractiveScene(cfg.scene, self.num_envs, device, env_origins, terrain)
+        self.scene.articulations["robot"] = Articulation(robot_cfg, self.physics, device)
+        robot = self.scene.articulations["robot"]
+        if getattr(cfg.scene, "contact_forces", None) is not None:
+            self.scene.sensors["contact_forces"] = ContactSensor(
+                cfg.scene.contact_forces, self.physics, robot.body_names, self.num_envs, device, self.physics_dt)
+        if getattr(cfg.scene, "height_scanner", None) is not None:
+            if mesh is None:
+                if terrain is None:
+                    raise ValueError("the height scanner needs a mesh or a terrain")
+                mesh = convert_to_warp_mesh(terrain.vertices, terrain.triangles, device)
+            self.mesh = mesh
+            rc = RayCaster(cfg.scene.height_scanner, self.physics, mesh, self.num_envs, device, self.physics_dt)
+            rc.bind_pose(lambda d=robot.data: d.root_state_w)
+            self.scene.sensors["height_scanner"] = rc
+        # -- counters
+        self.common_step_counter = 0
+        self.episode_length_buf = torch.zeros(self.num_envs, device=device, dtype=torch.long)
+        # -- managers (load order of manager_based_env.py / manager_based_rl_env.py:115-140)
+        self.command_manager = CommandManager(cfg.commands, self)
+        self.action_manager = ActionManager(cfg.actions, self)
+        self.termination_manager = TerminationManager(cfg.terminations, self)
+        self.observation_manager = ObservationManager(cfg.observations, self, seed=getattr(cfg, "seed", None))
+        self.reward_manager = RewardManager(cfg.rewards, self)
+        self.obs_buf = None
+        self.reward_buf = None
+        self.reset_buf = None
+        self.reset_terminated = None
+        self.reset_time_outs = None
+
+    # -- properties (manager_based_rl_env.py:93-102) ----------------------------------------------------
+    @property
+    def physics_dt(self) -> float:
+        return self.cfg.sim.dt
+
+    @property
+    def step_dt(self) -> float:
+        return self.cfg.sim.dt * self.cfg.decimation
+
+    @property
+    def max_episode_length_s(self) -> float:
+        return self.cfg.episode_length_s
+
+    @property
+    def max_episode_length(self) -> int:
+        return math.ceil(self.max_episode_length_s / self.step_dt)
+
+    # -- stepping -----------------------------------------------------------------------------------------
+    def step(self, action: torch.Tensor):
+        """manager_based_rl_env.py:152-241"""
+        self.action_manager.process_action(action.to(self.device))
+        for _ in range(self.cfg.decimation):
+            self.action_manager.apply_action()
+            self.scene.write_data_to_sim()
+            self.physics.advance()                      # sim.step(render=False): synthetic / replayed
+            self.scene.update(dt=self.physics_dt)
+        self.episode_length_buf += 1
+        self.common_step_counter += 1
+        self.reset_buf = self.termination_manager.compute()
+        self.reset_terminated = self.termination_manager.terminated
+        self.reset_time_outs = self.termination_manager.time_outs
+        self.reward_buf = self.reward_manager.compute(dt=self.step_dt)
+        if self.auto_reset:
+            reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+            if len(reset_env_ids) > 0:
+                self._reset_idx(reset_env_ids)
+        self.command_manager.compute(dt=self.step_dt)
+        self.obs_buf = self.observation_manager.compute()
+        return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    def _reset_idx(self, env_ids):
+        """manager_based_rl_env.py:346-391 without events / curriculum (out of scope)."""
+        self.scene.reset(env_ids)
+        self.extras["log"] = dict()
+        for manager in (self.observation_manager, self.action_manager, self.reward_manager,
+                        self.command_manager, self.termination_manager):
+            self.extras["log"].update(manager.reset(env_ids))
+        self.episode_length_buf[env_ids] = 0

@@ -1,0 +1,54 @@
+"""Scene container (``LAB/scene/interactive_scene.py:432-513`` subset): entity lookup by name,
+``write_data_to_sim`` / ``update`` / ``reset`` fan-out.  USD cloning / spawning is out of scope."""
+from __future__ import annotations
+
+import torch
+
+
+class InteractiveScene:
+    def __init__(self, cfg, num_envs: int, device: str, env_origins: torch.Tensor | None = None, terrain=None):
+        self.cfg = cfg
+        self.num_envs = num_envs
+        self.device = device
+        self.articulations: dict = dict()
+        self.rigid_objects: dict = dict()
+        self.sensors: dict = dict()
+        self.terrain = terrain
+        self.env_origins = (env_origins if env_origins is not None
+                            else torch.zeros((num_envs, 3), dtype=torch.float32, device=device))
+        self.lazy_sensor_update = True
+
+    def keys(self) -> list[str]:
+        keys = ["terrain"] if self.terrain is not None else []
+        for group in (self.articulations, self.rigid_objects, self.sensors):
+            keys += list(group.keys())
+        return keys
+
+    def __getitem__(self, key: str):
+        if key == "terrain":
+            return self.terrain
+        for group in (self.articulations, self.rigid_objects, self.sensors):
+            if key in group:
+                return group[key]
+        raise KeyError(f"Scene entity with key '{key}' not found. Available Entities: '{self.keys()}'")
+
+    def reset(self, env_ids=None):
+        for group in (self.articulations, self.rigid_objects, self.sensors):
+            for entity in group.values():
+                entity.reset(env_ids)
+
+    def write_data_to_sim(self):
+        """interactive_scene.py:484-494"""
+        for articulation in self.articulations.values():
+            articulation.write_data_to_sim()
+        for obj in self.rigid_objects.values():
+            obj.write_data_to_sim()
+
+    def update(self, dt: float) -> None:
+        """interactive_scene.py:496-513"""
+        for articulation in self.articulations.values():
+            articulation.update(dt)
+        for obj in self.rigid_objects.values():
+            obj.update(dt)
+        for sensor in self.sensors.values():
+            sensor.update(dt, force_recompute=not self.lazy_sensor_update)

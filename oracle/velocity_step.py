@@ -1,0 +1,221 @@
+"""CPU oracle of one full MDP env-step of the velocity task (TEST INFRASTRUCTURE; cpu_baseline of bench.py).
+
+Follows ``ManagerBasedRLEnv.step`` (``LAB/envs/manager_based_rl_env.py:152-241``): action processing ->
+decimation x {actuator, joint_acc, contact sensor} -> terminations -> rewards -> commands -> observations,
+with the term set of ``velocity_env_cfg.py`` (and the per-robot overrides) expressed as plain lists."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import actuators_np as A
+from . import math_np as M
+from . import mdp_np as P
+from .mdp_np import Terms as T
+
+F = np.float32
+
+
+class VelocityStepOracle:
+    def __init__(self, spec: dict):
+        """spec keys: num_envs, joint_names, body_names, default_joint_pos (J,), soft_limit_factor, joint_pos_limits,
+        actuator {kind, kp, kd, effort_limit, velocity_limit, saturation, [lstm_weights, decoder]},
+        rewards [(name, fn, weight)], terminations [(name, fn, time_out)], obs_terms [(name, fn, noise(a,b)|None, clip)],
+        command cfg dict, sim_dt, decimation, episode_length_s, env_origins, contact {history, period, threshold},
+        height_scan {starts, dirs, caster, update_period, offset_z} or None, action_scale."""
+        self.s = s = spec
+        n, j, b = s["num_envs"], len(s["joint_names"]), len(s["body_names"])
+        self.n, self.j, self.b = n, j, b
+        self.dt, self.dec = s["sim_dt"], s["decimation"]
+        self.step_dt = self.dt * self.dec
+        self.max_episode_length = math.ceil(s["episode_length_s"] / self.step_dt)
+        self.default_q = np.tile(np.asarray(s["default_joint_pos"], np.float32), (n, 1))
+        lo, hi = s["joint_pos_limits"]
+        mean, rng = (lo + hi) / 2, hi - lo
+        self.soft_limits = np.zeros((n, j, 2), np.float32)
+        self.soft_limits[..., 0] = mean - 0.5 * rng * s["soft_limit_factor"]
+        self.soft_limits[..., 1] = mean + 0.5 * rng * s["soft_limit_factor"]
+        self.action = np.zeros((n, j), np.float32)
+        self.prev_action = np.zeros((n, j), np.float32)
+        self.target = self.default_q.copy()
+        self.prev_qd = np.zeros((n, j), np.float32)
+        self.joint_acc = np.zeros((n, j), np.float32)
+        self.computed = np.zeros((n, j), np.float32)
+        self.applied = np.zeros((n, j), np.float32)
+        c = s["contact"]
+        self.contact = P.ContactSensor(n, b, c["history"], c["period"], c["threshold"])
+        self.command = P.VelocityCommand(n, s["command"], self.step_dt)
+        self.episode_length = np.zeros(n, np.int64)
+        nr = len(s["rewards"])
+        self.episode_sums = np.zeros((nr, n), np.float32)
+        self.step_reward = np.zeros((n, nr), np.float32)
+        self.term_dones = np.zeros((len(s["terminations"]), n), bool)
+        self.terminated = np.zeros(n, bool)
+        self.time_outs = np.zeros(n, bool)
+        hs = s.get("height_scan")
+        if hs is not None:
+            r = hs["starts"].shape[0]
+            self.ray_hits = np.zeros((n, r, 3), np.float32)
+            self.sensor_pos = np.zeros((n, 3), np.float32)
+            self.rc_ts = np.zeros(n, np.float32)
+            self.rc_last = np.zeros(n, np.float32)
+            self.rc_outdated = np.ones(n, bool)
+        act = s["actuator"]
+        if act["kind"] == "lstm":
+            L, H = len(act["lstm_weights"]), act["lstm_weights"][0][1].shape[1]
+            self.h = np.zeros((L, n * j, H), np.float32)
+            self.c = np.zeros((L, n * j, H), np.float32)
+
+    def env_dict(self, root_state, q, qd):
+        E = dict(root_state=root_state, joint_pos=q, joint_vel=qd, joint_acc=self.joint_acc,
+                 default_joint_pos=self.default_q, default_joint_vel=np.zeros_like(self.default_q),
+                 soft_joint_pos_limits=self.soft_limits,
+                 soft_joint_vel_limits=np.full((self.n, self.j), self.s["actuator"]["velocity_limit"], np.float32),
+                 applied_torque=self.applied, computed_torque=self.computed, action=self.action,
+                 prev_action=self.prev_action, command=self.command.cmd, contact_hist=self.contact.hist,
+                 cur_contact_time=self.contact.cur_con, cur_air_time=self.contact.cur_air,
+                 last_air_time=self.contact.last_air, step_dt=self.step_dt, terminated=self.terminated,
+                 time_outs=self.time_outs, term_dones=self.term_dones, episode_length_buf=self.episode_length,
+                 max_episode_length=self.max_episode_length, env_origins=self.s["env_origins"],
+                 time_left=self.command.time_left, command_counter=self.command.counter)
+        if self.s.get("height_scan") is not None:
+            E["ray_hits_w"] = self.ray_hits
+            E["sensor_pos_w"] = self.sensor_pos
+        return E
+
+    def _actuator(self, q, qd):
+        a = self.s["actuator"]
+        zeros = np.zeros_like(q)
+        if a["kind"] == "dc_motor":
+            self.computed, self.applied = A.dc_motor(self.target, zeros, zeros, q, qd, a["kp"], a["kd"],
+                                                     a["effort_limit"], a["velocity_limit"], a["saturation"])
+        elif a["kind"] in ("ideal_pd", "implicit"):
+            self.computed, self.applied = A.ideal_pd(self.target, zeros, zeros, q, qd, a["kp"], a["kd"], a["effort_limit"])
+        elif a["kind"] == "lstm":
+            lim = np.full_like(q, a["effort_limit"])
+            vl = np.full_like(q, a["velocity_limit"])
+            self.computed, self.applied, self.h, self.c = A.actuator_net_lstm(
+                self.target, q, qd, self.h, self.c, a["lstm_weights"], a["decoder"], lim, vl, a["saturation"])
+        else:
+            raise ValueError(a["kind"])
+
+    def _raycast(self, root_state):
+        hs = self.s["height_scan"]
+        ids = np.nonzero(self.rc_outdated)[0]
+        if ids.size == 0:
+            return
+        pos = root_state[ids, :3]
+        quat = root_state[ids, 3:7]
+        sw, dw = P.raycaster_rays(pos, quat, hs["starts"], hs["dirs"], True)
+        hits = hs["caster"].cast(sw.reshape(-1, 3), dw.reshape(-1, 3), 1e6, hs.get("threads", 0))[0]
+        self.ray_hits[ids] = hits.reshape(ids.size, -1, 3)
+        self.sensor_pos[ids] = pos
+        self.rc_last[ids] = self.rc_ts[ids]
+        self.rc_outdated[ids] = False
+
+    def step(self, action, substep_frames, cmd_uniforms=None, obs_noise=None):
+        """substep_frames: list of `decimation` dicts {root_state (N,13 wxyz), joint_pos, joint_vel, forces (N,B,3)}."""
+        s = self.s
+        self.prev_action = self.action.copy()
+        self.action = np.asarray(action, np.float32).copy()
+        self.target = (self.action * F(s["action_scale"]) + self.default_q).astype(np.float32)
+        for fr in substep_frames:  # write_data_to_sim uses the state of the PREVIOUS physics step
+            q, qd = self._last_q, self._last_qd
+            self._actuator(q, qd)
+            # physics.advance(): the new frame becomes current; scene.update(dt)
+            self._last_q, self._last_qd = fr["joint_pos"], fr["joint_vel"]
+            self.joint_acc = P.joint_acc(fr["joint_vel"], self.prev_qd, self.dt)
+            self.prev_qd = fr["joint_vel"].copy()
+            self.contact.update(fr["forces"], self.dt)
+            if s.get("height_scan") is not None:
+                self.rc_ts = (self.rc_ts + F(self.dt)).astype(np.float32)
+                self.rc_outdated |= (self.rc_ts - self.rc_last + F(1e-6)) >= F(s["height_scan"]["update_period"])
+        fr = substep_frames[-1]
+        root = fr["root_state"]
+        self.episode_length += 1
+        E = self.env_dict(root, fr["joint_pos"], fr["joint_vel"])
+        # terminations
+        vals = [fn(E) for _, fn, _ in s["terminations"]]
+        for i, v in enumerate(vals):
+            self.term_dones[i] = v
+        self.time_outs, self.terminated = P.termination_compute(vals, [to for _, _, to in s["terminations"]])
+        E["terminated"], E["time_outs"] = self.terminated, self.time_outs
+        # rewards (terms reading ray hits trigger the lazy sensor update first)
+        if s.get("height_scan") is not None and s.get("reward_needs_rays", False):
+            self._raycast(root)
+        values = [fn(E) if w != 0.0 else None for _, fn, w in s["rewards"]]
+        reward = P.reward_compute(values, [w for _, _, w in s["rewards"]], self.step_dt, self.episode_sums,
+                                  self.step_reward)
+        # commands
+        if cmd_uniforms is None:
+            cmd_uniforms = np.zeros((self.n, 7), np.float32)
+        self.command.compute(root, self.step_dt, cmd_uniforms)
+        E["command"] = self.command.cmd
+        # observations
+        if s.get("height_scan") is not None:
+            self._raycast(root)
+            E["ray_hits_w"], E["sensor_pos_w"] = self.ray_hits, self.sensor_pos
+        cols = []
+        for k, (name, fn, noise, clip) in enumerate(s["obs_terms"]):
+            v = fn(E)
+            nz = None
+            if noise is not None and obs_noise is not None:
+                nz = ("uniform", "add", noise[0], noise[1], obs_noise[name])
+            cols.append(P.obs_postprocess(v, nz, clip))
+        obs = np.concatenate(cols, axis=1)
+        return obs, reward, self.terminated.copy(), self.time_outs.copy()
+
+    def prime(self, joint_pos, joint_vel):
+        """State visible to the first write_data_to_sim (what the physics view holds before the first step)."""
+        self._last_q, self._last_qd = np.asarray(joint_pos, np.float32), np.asarray(joint_vel, np.float32)
+
+
+def anymal_spec(num_envs, env_origins, rough=True, caster=None, ray_starts=None, ray_dirs=None, actuator=None,
+                flat_weights=False, threads=0):
+    """Term tables of Isaac-Velocity-{Rough,Flat}-Anymal-D-v0 (velocity_env_cfg.py:116-265, flat_env_cfg.py:13-28)."""
+    legs = ("LF", "LH", "RF", "RH")
+    joint_names = [f"{l}_{j}" for j in ("HAA", "HFE", "KFE") for l in legs]
+    body_names = ["base"] + [f"{l}_{b}" for b in ("HIP", "THIGH", "SHANK", "FOOT") for l in legs]
+    dq = [0.0] * 4 + [0.4, -0.4, 0.4, -0.4] + [-0.8, 0.8, -0.8, 0.8]
+    feet = [i for i, b in enumerate(body_names) if b.endswith("FOOT")]
+    thighs = [i for i, b in enumerate(body_names) if b.endswith("THIGH")]
+    std = math.sqrt(0.25)
+    w_flat, w_tau, w_air = (-5.0, -2.5e-5, 0.5) if flat_weights else (0.0, -1.0e-5, 0.125)
+    rewards = [
+        ("track_lin_vel_xy_exp", lambda E: T.track_lin_vel_xy_exp(E, std), 1.0),
+        ("track_ang_vel_z_exp", lambda E: T.track_ang_vel_z_exp(E, std), 0.5),
+        ("lin_vel_z_l2", T.lin_vel_z_l2, -2.0),
+        ("ang_vel_xy_l2", T.ang_vel_xy_l2, -0.05),
+        ("dof_torques_l2", T.joint_torques_l2, w_tau),
+        ("dof_acc_l2", T.joint_acc_l2, -2.5e-7),
+        ("action_rate_l2", T.action_rate_l2, -0.01),
+        ("feet_air_time", lambda E: T.feet_air_time(E, 0.5, feet), w_air),
+        ("undesired_contacts", lambda E: T.undesired_contacts(E, 1.0, thighs), -1.0),
+        ("flat_orientation_l2", T.flat_orientation_l2, w_flat),
+        ("dof_pos_limits", T.joint_pos_limits, 0.0),
+    ]
+    terminations = [("time_out", T.time_out, True), ("base_contact", lambda E: T.illegal_contact(E, 1.0, [0]), False)]
+    obs_terms = [
+        ("base_lin_vel", T.base_lin_vel, (-0.1, 0.1), None), ("base_ang_vel", T.base_ang_vel, (-0.2, 0.2), None),
+        ("projected_gravity", T.projected_gravity, (-0.05, 0.05), None),
+        ("velocity_commands", T.generated_commands, None, None),
+        ("joint_pos", T.joint_pos_rel, (-0.01, 0.01), None), ("joint_vel", T.joint_vel_rel, (-1.5, 1.5), None),
+        ("actions", T.last_action, None, None),
+    ]
+    height = None
+    if rough:
+        obs_terms.append(("height_scan", T.height_scan, (-0.1, 0.1), (-1.0, 1.0)))
+        height = dict(starts=ray_starts, dirs=ray_dirs, caster=caster, update_period=0.02, threads=threads)
+    if actuator is None:
+        actuator = dict(kind="dc_motor", kp=F(40.0), kd=F(5.0), effort_limit=F(80.0), velocity_limit=F(7.5), saturation=120.0)
+    return dict(
+        num_envs=num_envs, joint_names=joint_names, body_names=body_names, default_joint_pos=dq,
+        soft_limit_factor=0.95, joint_pos_limits=(-2.4, 2.4), actuator=actuator, rewards=rewards,
+        terminations=terminations, obs_terms=obs_terms, sim_dt=0.005, decimation=4, episode_length_s=20.0,
+        env_origins=np.asarray(env_origins, np.float32), action_scale=0.5,
+        contact=dict(history=3, period=0.005, threshold=1.0), height_scan=height,
+        command=dict(resampling_time_range=(10.0, 10.0), lin_vel_x=(-1.0, 1.0), lin_vel_y=(-1.0, 1.0),
+                     ang_vel_z=(-1.0, 1.0), heading=(-math.pi, math.pi), heading_command=True,
+                     rel_heading_envs=1.0, rel_standing_envs=0.02, heading_control_stiffness=0.5),
+    )

@@ -1,0 +1,898 @@
+"""Generates the committed golden fixtures by running the REFERENCE implementation on CPU.
+
+Run in the build container only (needs /root/reference):  ``python tests/golden/make_golden.py``
+Outputs ``tests/golden/*.npz`` (inputs + reference outputs, fp32 / bool / int arrays; data only).
+The reference source, byte-code or stubs never travel: tests read only the ``.npz`` files.
+
+Coverage: math M1-M13, actuators A1-A7 + buffers, noise/modifiers (deterministic
+ones), state container S1, contact sensor S2, ray generation S3, term library T-obs/T-rew/T-rew-vel/T-term,
+managers G3-G5, velocity command G7 (RNG-free cases), joint action G8, in-hand env T-shadow.
+"""
+from __future__ import annotations
+
+import importlib
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_loader as R  # noqa: E402
+
+torch.set_num_threads(4)
+R.install_stubs()
+OUT = HERE
+
+
+def save(name, **arrays):
+    clean = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        clean[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **clean)
+    print(f"{name}: {len(clean)} arrays, {sum(a.nbytes for a in clean.values()) / 1024:.1f} KiB")
+
+
+def rand_quat(g, n):
+    q = torch.randn(n, 4, generator=g)
+    return q / q.norm(dim=-1, keepdim=True)
+
+
+# ================================================================================================
+def gen_math():
+    m = R.ref_math()
+    g = torch.Generator().manual_seed(101)
+    out = {}
+    for n in (1, 7, 64):
+        q1, q2 = rand_quat(g, n), rand_quat(g, n)
+        q1[::3] *= -1
+        v = torch.randn(n, 3, generator=g)
+        p = f"n{n}_"
+        out.update({p + "q1": q1, p + "q2": q2, p + "v": v})
+        out[p + "quat_mul"] = m.quat_mul(q1, q2)
+        out[p + "quat_conjugate"] = m.quat_conjugate(q1)
+        out[p + "quat_inv"] = m.quat_inv(q1 * 1.7)
+        out[p + "quat_unique"] = m.quat_unique(q1)
+        out[p + "quat_rotate"] = m.quat_rotate(q1, v)
+        out[p + "quat_rotate_inverse"] = m.quat_rotate_inverse(q1, v)
+        out[p + "quat_apply"] = m.quat_apply(q1, v)
+        out[p + "quat_apply_yaw"] = m.quat_apply_yaw(q1, v)
+        out[p + "yaw_quat"] = m.yaw_quat(q1)
+        rpy = (torch.rand(n, 3, generator=g) - 0.5) * 6.0
+        out[p + "rpy"] = rpy
+        out[p + "quat_from_euler_xyz"] = m.quat_from_euler_xyz(rpy[:, 0], rpy[:, 1], rpy[:, 2])
+        out[p + "euler_xyz_from_quat"] = torch.stack(m.euler_xyz_from_quat(q1), dim=-1)
+        out[p + "axis_angle_from_quat"] = m.axis_angle_from_quat(q1)
+        out[p + "quat_error_magnitude"] = m.quat_error_magnitude(q1, q2)
+        out[p + "quat_box_minus"] = m.quat_box_minus(q1, q2)
+        angle = (torch.rand(n, generator=g) - 0.5) * 6.0
+        axis = torch.randn(n, 3, generator=g)
+        out.update({p + "angle": angle, p + "axis": axis})
+        out[p + "quat_from_angle_axis"] = m.quat_from_angle_axis(angle, axis)
+        mat = m.matrix_from_quat(q1)
+        out[p + "matrix_from_quat"] = mat
+        out[p + "quat_from_matrix"] = m.quat_from_matrix(mat)
+        ang = (torch.rand(n, 5, generator=g) - 0.5) * 40.0
+        out[p + "angles"] = ang
+        out[p + "wrap_to_pi"] = m.wrap_to_pi(ang)
+        x = torch.randn(n, 6, generator=g)
+        lo = -1.0 - torch.rand(6, generator=g)
+        hi = 1.0 + torch.rand(6, generator=g)
+        out.update({p + "x": x, p + "lo": lo, p + "hi": hi})
+        out[p + "scale_transform"] = m.scale_transform(x, lo, hi)
+        out[p + "unscale_transform"] = m.unscale_transform(x, lo, hi)
+        out[p + "saturate"] = m.saturate(x * 2, lo, hi)
+        out[p + "normalize"] = m.normalize(x)
+        out[p + "copysign"] = m.copysign(2.5, x[:, 0])
+        t1, t2 = torch.randn(n, 3, generator=g), torch.randn(n, 3, generator=g)
+        out.update({p + "t1": t1, p + "t2": t2})
+        a, b = m.combine_frame_transforms(t1, q1, t2, q2)
+        out[p + "combine_frame_transforms"] = torch.cat([a, b], dim=-1)
+        a, b = m.subtract_frame_transforms(t1, q1, t2, q2)
+        out[p + "subtract_frame_transforms"] = torch.cat([a, b], dim=-1)
+        a, b = m.compute_pose_error(t1, q1, t2, q2, "axis_angle")
+        out[p + "compute_pose_error_aa"] = torch.cat([a, b], dim=-1)
+        a, b = m.compute_pose_error(t1, q1, t2, q2, "quat")
+        out[p + "compute_pose_error_quat"] = torch.cat([a, b], dim=-1)
+        delta = torch.randn(n, 6, generator=g) * 0.3
+        delta[::4, 3:] = 0.0
+        out[p + "delta"] = delta
+        a, b = m.apply_delta_pose(t1, q1, delta)
+        out[p + "apply_delta_pose"] = torch.cat([a, b], dim=-1)
+        out[p + "skew_symmetric_matrix"] = m.skew_symmetric_matrix(v)
+        pts = torch.randn(n, 5, 3, generator=g)
+        out[p + "pts"] = pts
+        out[p + "transform_points"] = m.transform_points(pts, t1, q1)
+    save("math", **out)
+
+
+# ================================================================================================
+def _act_common(g, n, j):
+    return dict(q_des=torch.randn(n, j, generator=g) * 0.5, qd_des=torch.randn(n, j, generator=g) * 0.1,
+                tau_ff=torch.randn(n, j, generator=g) * 2.0, q=torch.randn(n, j, generator=g) * 0.5,
+                qd=torch.randn(n, j, generator=g) * 4.0)
+
+
+def gen_actuators():
+    act = R.ref_import("isaaclab.actuators")
+    from isaaclab.utils.types import ArticulationActions
+
+    g = torch.Generator().manual_seed(202)
+    out = {}
+    names = [f"j{i}" for i in range(12)]
+    for n in (1, 7, 64):
+        for kind, cls, cfgcls, extra in (
+            ("implicit", act.ImplicitActuator, act.ImplicitActuatorCfg, {}),
+            ("ideal_pd", act.IdealPDActuator, act.IdealPDActuatorCfg, {}),
+            ("dc_motor", act.DCMotor, act.DCMotorCfg, {"saturation_effort": 120.0}),
+        ):
+            cfg = cfgcls(joint_names_expr=[".*"], effort_limit=80.0, velocity_limit=7.5, stiffness={".*": 40.0},
+                         damping={".*": 5.0}, **extra)
+            a = cls(cfg, names, slice(None), n, "cpu")
+            io = _act_common(g, n, 12)
+            io["qd"][0, 0] = 7.5  # hits the zero of the DC-motor characteristic exactly
+            ca = ArticulationActions(joint_positions=io["q_des"].clone(), joint_velocities=io["qd_des"].clone(),
+                                     joint_efforts=io["tau_ff"].clone())
+            a.compute(ca, io["q"], io["qd"])
+            p = f"{kind}_n{n}_"
+            out.update({p + k: v for k, v in io.items()})
+            out[p + "computed"] = a.computed_effort
+            out[p + "applied"] = a.applied_effort
+    # DC motor with saturation = inf (cfg None)
+    cfg = act.DCMotorCfg(joint_names_expr=[".*"], effort_limit=80.0, velocity_limit=7.5, stiffness=40.0, damping=5.0,
+                         saturation_effort=None)
+    a = act.DCMotor(cfg, names, slice(None), 7, "cpu")
+    io = _act_common(g, 7, 12)
+    ca = ArticulationActions(joint_positions=io["q_des"].clone(), joint_velocities=io["qd_des"].clone(),
+                             joint_efforts=io["tau_ff"].clone())
+    a.compute(ca, io["q"], io["qd"])
+    out.update({"dc_inf_" + k: v for k, v in io.items()})
+    out["dc_inf_computed"], out["dc_inf_applied"] = a.computed_effort, a.applied_effort
+
+    # delayed PD: sequence of 6 computes, fixed lags injected (reset draws them with randint)
+    n, j = 7, 4
+    cfg = act.DelayedPDActuatorCfg(joint_names_expr=[".*"], effort_limit=50.0, velocity_limit=10.0, stiffness=20.0,
+                                   damping=1.0, min_delay=0, max_delay=3)
+    a = act.DelayedPDActuator(cfg, names[:j], slice(None), n, "cpu")
+    lags = torch.tensor([0, 1, 2, 3, 3, 1, 0], dtype=torch.int)
+    for buf in (a.positions_delay_buffer, a.velocities_delay_buffer, a.efforts_delay_buffer):
+        buf.set_time_lag(lags)
+        buf.reset()
+    out["delayed_lags"] = lags
+    seq_in, seq_comp, seq_app = [], [], []
+    for t in range(6):
+        io = _act_common(g, n, j)
+        ca = ArticulationActions(joint_positions=io["q_des"].clone(), joint_velocities=io["qd_des"].clone(),
+                                 joint_efforts=io["tau_ff"].clone())
+        a.compute(ca, io["q"], io["qd"])
+        seq_in.append(torch.stack([io[k] for k in ("q_des", "qd_des", "tau_ff", "q", "qd")]))
+        seq_comp.append(a.computed_effort.clone())
+        seq_app.append(a.applied_effort.clone())
+        if t == 3:  # partial reset in the middle of the sequence
+            for buf in (a.positions_delay_buffer, a.velocities_delay_buffer, a.efforts_delay_buffer):
+                buf.reset([1, 4])
+    out["delayed_inputs"] = torch.stack(seq_in)
+    out["delayed_computed"] = torch.stack(seq_comp)
+    out["delayed_applied"] = torch.stack(seq_app)
+
+    # remotized PD
+    lut = [[-1.0, 1.0, 20.0], [-0.5, 1.0, 35.0], [0.0, 1.0, 50.0], [0.7, 1.0, 30.0], [1.2, 1.0, 10.0]]
+    cfg = act.RemotizedPDActuatorCfg(joint_names_expr=[".*"], stiffness=60.0, damping=2.0, min_delay=0, max_delay=0,
+                                     joint_parameter_lookup=lut)
+    a = act.RemotizedPDActuator(cfg, names[:j], slice(None), n, "cpu")
+    a.reset(slice(None))
+    io = _act_common(g, n, j)
+    io["q"][0, 0], io["q"][1, 1], io["q"][2, 2] = -2.0, 2.0, -0.5
+    ca = ArticulationActions(joint_positions=io["q_des"].clone(), joint_velocities=io["qd_des"].clone(),
+                             joint_efforts=io["tau_ff"].clone())
+    a.compute(ca, io["q"], io["qd"])
+    out.update({"remotized_" + k: v for k, v in io.items()})
+    out["remotized_lut"] = torch.tensor(lut)
+    out["remotized_computed"], out["remotized_applied"] = a.computed_effort, a.applied_effort
+
+    # actuator nets: locally built TorchScript modules with seeded random weights (the real files are remote)
+    class SeaNet(torch.nn.Module):
+        def __init__(self, hidden, layers, dec):
+            super().__init__()
+            self.lstm = torch.nn.LSTM(2, hidden, layers, batch_first=True)
+            mods, d = [], hidden
+            for w in dec:
+                mods += [torch.nn.Linear(d, w), torch.nn.ELU()]
+                d = w
+            mods.append(torch.nn.Linear(d, 1))
+            self.decoder = torch.nn.Sequential(*mods)
+
+        def forward(self, x, hc: tuple[torch.Tensor, torch.Tensor]):
+            o, (h, c) = self.lstm(x, hc)
+            return self.decoder(o[:, -1, :]), (h, c)
+
+    for tag, hidden, layers, dec in (("lstm8", 8, 2, []), ("lstm16", 16, 1, [32])):
+        torch.manual_seed(303 + hidden)
+        net = torch.jit.script(SeaNet(hidden, layers, dec))
+        import io as _io
+
+        buf = _io.BytesIO()
+        torch.jit.save(net, buf)
+        blob = buf.getvalue()
+        n, j = 7, 12
+        cfg = act.ActuatorNetLSTMCfg(joint_names_expr=[".*"], network_file="unused", saturation_effort=120.0,
+                                     effort_limit=80.0, velocity_limit=7.5)
+        import isaaclab.actuators.actuator_net as an
+
+        an.read_file = lambda path, _b=blob: _io.BytesIO(_b)
+        a = act.ActuatorNetLSTM(cfg, names, slice(None), n, "cpu")
+        seq_in, seq_comp, seq_app, seq_h, seq_c = [], [], [], [], []
+        for t in range(4):
+            io = _act_common(g, n, j)
+            ca = ArticulationActions(joint_positions=io["q_des"].clone(), joint_velocities=None, joint_efforts=None)
+            a.compute(ca, io["q"], io["qd"])
+            seq_in.append(torch.stack([io["q_des"], io["q"], io["qd"]]))
+            seq_comp.append(a.computed_effort.clone())
+            seq_app.append(a.applied_effort.clone())
+            seq_h.append(a.sea_hidden_state.clone())
+            seq_c.append(a.sea_cell_state.clone())
+            if t == 1:
+                a.reset([2, 5])
+                seq_h[-1] = a.sea_hidden_state.clone()
+                seq_c[-1] = a.sea_cell_state.clone()
+        for k, v in net.state_dict().items():
+            out[f"{tag}_w_{k}"] = v
+        out[f"{tag}_inputs"] = torch.stack(seq_in)
+        out[f"{tag}_computed"] = torch.stack(seq_comp)
+        out[f"{tag}_applied"] = torch.stack(seq_app)
+        out[f"{tag}_h"] = torch.stack(seq_h)
+        out[f"{tag}_c"] = torch.stack(seq_c)
+
+    # MLP net (Go1-like: taps [0,1,2], 6 -> 32 -> 32 -> 1, softsign), pos_scale -1
+    torch.manual_seed(404)
+    mlp = torch.jit.script(torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Softsign(), torch.nn.Linear(32, 32),
+                                               torch.nn.Softsign(), torch.nn.Linear(32, 1)))
+    import io as _io
+
+    buf = _io.BytesIO()
+    torch.jit.save(mlp, buf)
+    blob = buf.getvalue()
+    import isaaclab.actuators.actuator_net as an
+
+    an.read_file = lambda path, _b=blob: _io.BytesIO(_b)
+    for order in ("pos_vel", "vel_pos"):
+        cfg = act.ActuatorNetMLPCfg(joint_names_expr=[".*"], network_file="unused", saturation_effort=23.7,
+                                    effort_limit=23.7, velocity_limit=30.0, pos_scale=-1.0, vel_scale=1.0,
+                                    torque_scale=1.0, input_order=order, input_idx=[0, 1, 2])
+        n, j = 7, 12
+        a = act.ActuatorNetMLP(cfg, names, slice(None), n, "cpu")
+        seq_in, seq_comp, seq_app = [], [], []
+        for t in range(5):
+            io = _act_common(g, n, j)
+            ca = ArticulationActions(joint_positions=io["q_des"].clone(), joint_velocities=None, joint_efforts=None)
+            a.compute(ca, io["q"], io["qd"])
+            seq_in.append(torch.stack([io["q_des"], io["q"], io["qd"]]))
+            seq_comp.append(a.computed_effort.clone())
+            seq_app.append(a.applied_effort.clone())
+            if t == 2:
+                a.reset([0, 3])
+        out[f"mlp_{order}_inputs"] = torch.stack(seq_in)
+        out[f"mlp_{order}_computed"] = torch.stack(seq_comp)
+        out[f"mlp_{order}_applied"] = torch.stack(seq_app)
+    for k, v in mlp.state_dict().items():
+        out[f"mlp_w_{k}"] = v
+    save("actuators", **out)
+
+
+# ================================================================================================
+def gen_buffers_noise_modifiers():
+    from isaaclab.utils.buffers import CircularBuffer, DelayBuffer
+    from isaaclab.utils.interpolation import LinearInterpolation
+    import isaaclab.utils.modifiers as mods
+    import isaaclab.utils.noise as noise
+
+    g = torch.Generator().manual_seed(505)
+    out = {}
+    cb = CircularBuffer(4, 5, "cpu")
+    data = torch.randn(7, 5, 3, generator=g)
+    bufs = []
+    for t in range(7):
+        cb.append(data[t])
+        bufs.append(cb.buffer.clone())
+        if t == 3:
+            cb.reset([1, 3])
+    out["cb_data"] = data
+    out["cb_buffers"] = torch.stack(bufs)
+    out["cb_lookup"] = cb[torch.tensor([0, 1, 2, 3, 9])]
+    db = DelayBuffer(3, 5, "cpu")
+    db.set_time_lag(torch.tensor([0, 1, 2, 3, 2], dtype=torch.int))
+    outs = []
+    for t in range(7):
+        outs.append(db.compute(data[t]).clone())
+        if t == 4:
+            db.reset([0, 4])
+    out["db_out"] = torch.stack(outs)
+    x = torch.tensor([-1.0, -0.2, 0.3, 0.35, 2.0])
+    y = torch.tensor([3.0, 1.0, -2.0, 4.0, 0.5])
+    q = torch.cat([torch.randn(40, generator=g) * 1.5, x])
+    out.update({"li_x": x, "li_y": y, "li_q": q, "li_out": LinearInterpolation(x, y, "cpu").compute(q)})
+    d = torch.randn(6, 4, generator=g)
+    out["mod_data"] = d
+    out["mod_scale"] = mods.scale(d, 1.7)
+    out["mod_clip"] = mods.clip(d, (-0.5, None))
+    out["mod_bias"] = mods.bias(d, 0.3)
+    out["noise_const_add"] = noise.constant_noise(d, noise.ConstantNoiseCfg(bias=0.25))
+    out["noise_const_scale"] = noise.constant_noise(d, noise.ConstantNoiseCfg(bias=0.25, operation="scale"))
+    out["noise_const_abs"] = noise.constant_noise(d, noise.ConstantNoiseCfg(bias=0.25, operation="abs"))
+    fcfg = mods.DigitalFilterCfg(A=[0.3, -0.1], B=[0.5, 0.2, 0.1])
+    filt = mods.DigitalFilter(fcfg, (6, 4), "cpu")
+    icfg = mods.IntegratorCfg(dt=0.02)
+    integ = mods.Integrator(icfg, (6, 4), "cpu")
+    seq = torch.randn(5, 6, 4, generator=g)
+    fo, io_ = [], []
+    for t in range(5):
+        fo.append(filt(seq[t]).clone())
+        io_.append(integ(seq[t]).clone())
+        if t == 2:
+            filt.reset([0, 5])
+            integ.reset([0, 5])
+    out.update({"mod_seq": seq, "mod_filter": torch.stack(fo), "mod_integrator": torch.stack(io_)})
+    save("buffers_noise_modifiers", **out)
+
+
+# ================================================================================================
+class _NS(types.SimpleNamespace):
+    pass
+
+
+def make_state(g, n, j=12, b=17, h=3, r=11):
+    st = torch.zeros(n, 13)
+    st[:, :3] = torch.randn(n, 3, generator=g) * torch.tensor([3.0, 3.0, 0.1]) + torch.tensor([0.0, 0.0, 0.6])
+    st[:, 3:7] = rand_quat(g, n)
+    st[:, 7:] = torch.randn(n, 6, generator=g) * 0.5
+    d = dict(
+        root_state=st, joint_pos=torch.randn(n, j, generator=g) * 0.6, joint_vel=torch.randn(n, j, generator=g) * 3.0,
+        joint_acc=torch.randn(n, j, generator=g) * 20.0, default_joint_pos=torch.randn(n, j, generator=g) * 0.3,
+        default_joint_vel=torch.zeros(n, j), applied_torque=torch.randn(n, j, generator=g) * 30.0,
+        action=torch.randn(n, j, generator=g), prev_action=torch.randn(n, j, generator=g),
+        command=torch.randn(n, 3, generator=g), env_origins=torch.randn(n, 3, generator=g) * 5.0,
+        body_state=torch.randn(n, b, 13, generator=g), body_acc=torch.randn(n, b, 6, generator=g) * 3.0,
+        soft_joint_vel_limits=torch.full((n, j), 2.5) + torch.rand(n, j, generator=g),
+    )
+    d["computed_torque"] = d["applied_torque"].clone()
+    mask = torch.rand(n, j, generator=g) < 0.4
+    d["computed_torque"][mask] += torch.randn(int(mask.sum()), generator=g) * 10.0
+    lim = torch.zeros(n, j, 2)
+    lim[..., 0] = -0.8 - torch.rand(n, j, generator=g) * 0.3
+    lim[..., 1] = 0.8 + torch.rand(n, j, generator=g) * 0.3
+    d["soft_joint_pos_limits"] = lim
+    hist = torch.randn(n, h, b, 3, generator=g) * 0.8
+    hist[torch.rand(n, h, b, generator=g) < 0.3] *= 20.0
+    d["contact_hist"] = hist
+    for k in ("cur_air", "cur_contact", "last_air", "last_contact"):
+        t = torch.rand(n, b, generator=g) * 0.6
+        d[k] = t
+    on = torch.rand(n, b, generator=g) < 0.5
+    d["cur_contact"] = torch.where(on, d["cur_contact"] * 0.08, torch.zeros_like(on, dtype=torch.float))
+    d["cur_air"] = torch.where(on, torch.zeros_like(on, dtype=torch.float), d["cur_air"])
+    d["ray_hits"] = torch.randn(n, r, 3, generator=g)
+    d["ray_hits"][0, 0, :] = float("inf")
+    d["sensor_pos"] = st[:, :3] + torch.tensor([0.0, 0.0, 20.0])
+    d["episode_length"] = torch.randint(0, 1200, (n,), generator=g)
+    d["time_left"] = torch.rand(n, generator=g) * 0.05
+    d["command_counter"] = torch.randint(0, 3, (n,), generator=g)
+    d["terminated"] = torch.rand(n, generator=g) < 0.3
+    d["time_outs"] = torch.rand(n, generator=g) < 0.3
+    d["term_dones"] = torch.rand(3, n, generator=g) < 0.4
+    return d
+
+
+def make_env(d, math_mod):
+    """Duck-typed env over the state dict (the reference's own manager tests mock the env the same way)."""
+    n = d["root_state"].shape[0]
+    st = d["root_state"]
+    data = _NS(
+        root_pos_w=st[:, :3], root_quat_w=st[:, 3:7], root_lin_vel_w=st[:, 7:10], root_ang_vel_w=st[:, 10:13],
+        root_lin_vel_b=math_mod.quat_rotate_inverse(st[:, 3:7], st[:, 7:10]),
+        root_ang_vel_b=math_mod.quat_rotate_inverse(st[:, 3:7], st[:, 10:13]),
+        projected_gravity_b=math_mod.quat_rotate_inverse(st[:, 3:7], torch.tensor([0.0, 0.0, -1.0]).repeat(n, 1)),
+        joint_pos=d["joint_pos"], joint_vel=d["joint_vel"], joint_acc=d["joint_acc"],
+        default_joint_pos=d["default_joint_pos"], default_joint_vel=d["default_joint_vel"],
+        soft_joint_pos_limits=d["soft_joint_pos_limits"], soft_joint_vel_limits=d["soft_joint_vel_limits"],
+        applied_torque=d["applied_torque"], computed_torque=d["computed_torque"],
+        body_lin_acc_w=d["body_acc"][..., :3], body_lin_vel_w=d["body_state"][..., 7:10],
+    )
+    robot = _NS(data=data)
+    contact = _NS(
+        data=_NS(net_forces_w_history=d["contact_hist"], current_air_time=d["cur_air"],
+                 current_contact_time=d["cur_contact"], last_air_time=d["last_air"], last_contact_time=d["last_contact"]),
+        compute_first_contact=lambda dt, abs_tol=1.0e-8: (d["cur_contact"] > 0.0) * (d["cur_contact"] < (dt + abs_tol)),
+    )
+    rays = _NS(data=_NS(pos_w=d["sensor_pos"], ray_hits_w=d["ray_hits"]))
+
+    class Scene(dict):
+        pass
+
+    scene = Scene(robot=robot, height_scanner=rays, contact_forces=contact)
+    scene.sensors = {"height_scanner": rays, "contact_forces": contact}
+    scene.env_origins = d["env_origins"]
+    term_names = ["time_out", "base_contact", "bad"]
+    env = _NS(
+        num_envs=n, device="cpu", scene=scene, step_dt=0.02, max_episode_length=1000, max_episode_length_s=20.0,
+        episode_length_buf=d["episode_length"],
+        action_manager=_NS(action=d["action"], prev_action=d["prev_action"]),
+        command_manager=_NS(get_command=lambda name: d["command"],
+                            get_term=lambda name: _NS(time_left=d["time_left"], command_counter=d["command_counter"])),
+        termination_manager=_NS(terminated=d["terminated"], time_outs=d["time_outs"],
+                                get_term=lambda name: d["term_dones"][term_names.index(name)],
+                                find_terms=lambda keys: term_names[:2], active_terms=term_names),
+    )
+    return env
+
+
+def gen_terms():
+    m = R.ref_math()
+    obs = R.ref_mdp("observations")
+    rew = R.ref_mdp("rewards")
+    term = R.ref_mdp("terminations")
+    vrew = R.ref_velocity_mdp("rewards")
+    from isaaclab.managers import SceneEntityCfg
+
+    g = torch.Generator().manual_seed(606)
+    out = {}
+    feet, thighs, some_j = [13, 14, 15, 16], [5, 6, 7, 8], [0, 3, 7, 11]
+
+    def cfg(name, joint_ids=None, body_ids=None):
+        c = SceneEntityCfg(name)
+        if joint_ids is not None:
+            c.joint_ids = joint_ids
+        if body_ids is not None:
+            c.body_ids = body_ids
+        return c
+
+    for n in (1, 7, 64):
+        d = make_state(g, n)
+        env = make_env(d, m)
+        p = f"n{n}_"
+        out.update({p + "in_" + k: v for k, v in d.items()})
+        O = {
+            "base_pos_z": obs.base_pos_z(env), "base_lin_vel": obs.base_lin_vel(env),
+            "base_ang_vel": obs.base_ang_vel(env), "projected_gravity": obs.projected_gravity(env),
+            "root_pos_w": obs.root_pos_w(env), "root_quat_w": obs.root_quat_w(env),
+            "root_quat_w_unique": obs.root_quat_w(env, make_quat_unique=True),
+            "root_lin_vel_w": obs.root_lin_vel_w(env), "root_ang_vel_w": obs.root_ang_vel_w(env),
+            "joint_pos": obs.joint_pos(env), "joint_pos_sel": obs.joint_pos(env, cfg("robot", some_j)),
+            "joint_pos_rel": obs.joint_pos_rel(env), "joint_pos_rel_sel": obs.joint_pos_rel(env, cfg("robot", some_j)),
+            "joint_pos_limit_normalized": obs.joint_pos_limit_normalized(env),
+            "joint_vel": obs.joint_vel(env), "joint_vel_rel": obs.joint_vel_rel(env),
+            "height_scan": obs.height_scan(env, cfg("height_scanner")), "last_action": obs.last_action(env),
+            "generated_commands": obs.generated_commands(env, "base_velocity"),
+        }
+        out.update({p + "obs_" + k: v for k, v in O.items()})
+        itt = rew.is_terminated_term(types.SimpleNamespace(params={"term_keys": ".*"}), env)
+        Rw = {
+            "is_alive": rew.is_alive(env), "is_terminated": rew.is_terminated(env), "is_terminated_term": itt(env),
+            "lin_vel_z_l2": rew.lin_vel_z_l2(env), "ang_vel_xy_l2": rew.ang_vel_xy_l2(env),
+            "flat_orientation_l2": rew.flat_orientation_l2(env), "base_height_l2": rew.base_height_l2(env, 0.55),
+            "base_height_l2_sensor": rew.base_height_l2(env, 0.55, sensor_cfg=cfg("height_scanner")),
+            "body_lin_acc_l2": rew.body_lin_acc_l2(env, cfg("robot", body_ids=feet)),
+            "joint_torques_l2": rew.joint_torques_l2(env), "joint_vel_l1": rew.joint_vel_l1(env, cfg("robot", some_j)),
+            "joint_vel_l2": rew.joint_vel_l2(env), "joint_acc_l2": rew.joint_acc_l2(env),
+            "joint_deviation_l1": rew.joint_deviation_l1(env, cfg("robot", some_j)),
+            "joint_pos_limits": rew.joint_pos_limits(env), "joint_vel_limits": rew.joint_vel_limits(env, 0.9),
+            "applied_torque_limits": rew.applied_torque_limits(env), "action_rate_l2": rew.action_rate_l2(env),
+            "action_l2": rew.action_l2(env),
+            "undesired_contacts": rew.undesired_contacts(env, 1.0, cfg("contact_forces", body_ids=thighs)),
+            "contact_forces": rew.contact_forces(env, 1.0, cfg("contact_forces", body_ids=feet)),
+            "track_lin_vel_xy_exp": rew.track_lin_vel_xy_exp(env, math.sqrt(0.25), "base_velocity"),
+            "track_ang_vel_z_exp": rew.track_ang_vel_z_exp(env, math.sqrt(0.25), "base_velocity"),
+            "feet_air_time": vrew.feet_air_time(env, "base_velocity", cfg("contact_forces", body_ids=feet), 0.5),
+            "feet_air_time_positive_biped": vrew.feet_air_time_positive_biped(
+                env, "base_velocity", 0.4, cfg("contact_forces", body_ids=feet[:2])),
+            "feet_slide": vrew.feet_slide(env, cfg("contact_forces", body_ids=feet), cfg("robot", body_ids=feet)),
+            "track_lin_vel_xy_yaw_frame_exp": vrew.track_lin_vel_xy_yaw_frame_exp(env, 0.5, "base_velocity"),
+            "track_ang_vel_z_world_exp": vrew.track_ang_vel_z_world_exp(env, "base_velocity", 0.5),
+        }
+        out.update({p + "rew_" + k: v.float() for k, v in Rw.items()})
+        Tm = {
+            "time_out": term.time_out(env), "command_resample": term.command_resample(env, "base_velocity", 1),
+            "bad_orientation": term.bad_orientation(env, 1.0),
+            "root_height_below_minimum": term.root_height_below_minimum(env, 0.55),
+            "joint_pos_out_of_manual_limit": term.joint_pos_out_of_manual_limit(env, (-0.9, 0.9), cfg("robot", some_j)),
+            "joint_vel_out_of_limit": term.joint_vel_out_of_limit(env),
+            "joint_vel_out_of_manual_limit": term.joint_vel_out_of_manual_limit(env, 6.0),
+            "joint_effort_out_of_limit": term.joint_effort_out_of_limit(env, cfg("robot", some_j)),
+            "illegal_contact": term.illegal_contact(env, 1.0, cfg("contact_forces", body_ids=[0])),
+        }
+        out.update({p + "term_" + k: v for k, v in Tm.items()})
+        try:
+            term.joint_pos_out_of_limit(env)
+            out[p + "term_joint_pos_out_of_limit_raises"] = np.array(0)
+        except IndexError:
+            out[p + "term_joint_pos_out_of_limit_raises"] = np.array(1)
+    save("terms", **out)
+
+
+# ================================================================================================
+def gen_managers():
+    """Reward / termination / observation managers of the reference driven by the duck-typed env with the
+    velocity-task term tables (flat + rough variants), two consecutive computes."""
+    m = R.ref_math()
+    obs = R.ref_mdp("observations")
+    rew = R.ref_mdp("rewards")
+    term = R.ref_mdp("terminations")
+    vrew = R.ref_velocity_mdp("rewards")
+    mg = R.ref_import("isaaclab.managers")
+    from isaaclab.managers import SceneEntityCfg
+    from isaaclab.utils.noise import ConstantNoiseCfg
+
+    g = torch.Generator().manual_seed(707)
+    out = {}
+    feet, thighs = [13, 14, 15, 16], [5, 6, 7, 8]
+
+    def ent(name, body_ids=None):
+        c = SceneEntityCfg(name)
+        if body_ids is not None:
+            c.body_ids = body_ids
+        c.resolve = lambda scene: None
+        return c
+
+    for n in (7, 64):
+        d = make_state(g, n)
+        env = make_env(d, m)
+        p = f"n{n}_"
+        out.update({p + "in_" + k: v for k, v in d.items()})
+        rcfg = {
+            "track_lin_vel_xy_exp": mg.RewardTermCfg(func=rew.track_lin_vel_xy_exp, weight=1.0,
+                                                     params={"command_name": "base_velocity", "std": math.sqrt(0.25)}),
+            "track_ang_vel_z_exp": mg.RewardTermCfg(func=rew.track_ang_vel_z_exp, weight=0.5,
+                                                    params={"command_name": "base_velocity", "std": math.sqrt(0.25)}),
+            "lin_vel_z_l2": mg.RewardTermCfg(func=rew.lin_vel_z_l2, weight=-2.0),
+            "ang_vel_xy_l2": mg.RewardTermCfg(func=rew.ang_vel_xy_l2, weight=-0.05),
+            "dof_torques_l2": mg.RewardTermCfg(func=rew.joint_torques_l2, weight=-1.0e-5),
+            "dof_acc_l2": mg.RewardTermCfg(func=rew.joint_acc_l2, weight=-2.5e-7),
+            "action_rate_l2": mg.RewardTermCfg(func=rew.action_rate_l2, weight=-0.01),
+            "feet_air_time": mg.RewardTermCfg(func=vrew.feet_air_time, weight=0.125,
+                                              params={"sensor_cfg": ent("contact_forces", feet),
+                                                      "command_name": "base_velocity", "threshold": 0.5}),
+            "undesired_contacts": mg.RewardTermCfg(func=rew.undesired_contacts, weight=-1.0,
+                                                   params={"sensor_cfg": ent("contact_forces", thighs), "threshold": 1.0}),
+            "flat_orientation_l2": mg.RewardTermCfg(func=rew.flat_orientation_l2, weight=0.0),
+            "dof_pos_limits": mg.RewardTermCfg(func=rew.joint_pos_limits, weight=0.0),
+        }
+        rm = mg.RewardManager(rcfg, env)
+        r1 = rm.compute(0.02).clone()
+        r2 = rm.compute(0.02).clone()
+        out[p + "reward_1"], out[p + "reward_2"] = r1, r2
+        out[p + "episode_sums"] = torch.stack([rm._episode_sums[k] for k in rm.active_terms])
+        out[p + "step_reward"] = rm._step_reward
+        tcfg = {
+            "time_out": mg.TerminationTermCfg(func=term.time_out, time_out=True),
+            "base_contact": mg.TerminationTermCfg(func=term.illegal_contact,
+                                                  params={"sensor_cfg": ent("contact_forces", [0]), "threshold": 1.0}),
+            "bad": mg.TerminationTermCfg(func=term.bad_orientation, params={"limit_angle": 1.0}),
+        }
+        tm = mg.TerminationManager(tcfg, env)
+        out[p + "dones"] = tm.compute().clone()
+        out[p + "terminated"], out[p + "time_outs"] = tm.terminated, tm.time_outs
+        out[p + "term_dones"] = torch.stack([tm.get_term(k) for k in tm.active_terms])
+
+        # observation manager: corruption with the deterministic constant-noise model + clip + scale
+        grp = mg.ObservationGroupCfg()
+        grp.enable_corruption = True
+        grp.concatenate_terms = True
+        grp.base_lin_vel = mg.ObservationTermCfg(func=obs.base_lin_vel, noise=ConstantNoiseCfg(bias=0.05))
+        grp.base_ang_vel = mg.ObservationTermCfg(func=obs.base_ang_vel, scale=0.25)
+        grp.projected_gravity = mg.ObservationTermCfg(func=obs.projected_gravity, clip=(-0.5, 0.5))
+        grp.velocity_commands = mg.ObservationTermCfg(func=obs.generated_commands, params={"command_name": "base_velocity"})
+        grp.joint_pos = mg.ObservationTermCfg(func=obs.joint_pos_rel, noise=ConstantNoiseCfg(bias=1.1, operation="scale"))
+        grp.joint_vel = mg.ObservationTermCfg(func=obs.joint_vel_rel, scale=tuple(0.05 * (i + 1) for i in range(12)))
+        grp.actions = mg.ObservationTermCfg(func=obs.last_action)
+        grp.height_scan = mg.ObservationTermCfg(func=obs.height_scan, params={"sensor_cfg": ent("height_scanner")},
+                                                noise=ConstantNoiseCfg(bias=-0.02), clip=(-1.0, 1.0))
+        om = mg.ObservationManager({"policy": grp}, env)
+        out[p + "obs"] = om.compute()["policy"]
+        # history variant (unfused path): 3-step history on two terms, two pushes
+        grp2 = mg.ObservationGroupCfg()
+        grp2.concatenate_terms = True
+        grp2.enable_corruption = False
+        grp2.history_length = 3
+        grp2.flatten_history_dim = True
+        grp2.base_lin_vel = mg.ObservationTermCfg(func=obs.base_lin_vel)
+        grp2.joint_pos = mg.ObservationTermCfg(func=obs.joint_pos_rel)
+        om2 = mg.ObservationManager({"policy": grp2}, env)
+        h1 = om2.compute()["policy"].clone()
+        d["joint_pos"] += 0.1
+        h2 = om2.compute()["policy"].clone()
+        d["joint_pos"] -= 0.1
+        out[p + "obs_hist_1"], out[p + "obs_hist_2"] = h1, h2
+    save("managers", **out)
+
+
+# ================================================================================================
+def gen_sensors_state():
+    m = R.ref_math()
+    cs = importlib.import_module("isaaclab.sensors.contact_sensor.contact_sensor")
+    sb = importlib.import_module("isaaclab.sensors.sensor_base")
+    rc = importlib.import_module("isaaclab.sensors.ray_caster.ray_caster")
+    pt = importlib.import_module("isaaclab.sensors.ray_caster.patterns.patterns")
+    ad = importlib.import_module("isaaclab.assets.articulation.articulation_data")
+    g = torch.Generator().manual_seed(808)
+    out = {}
+
+    # ---- contact sensor: reference update code run on a fake self ----
+    n, b, h = 7, 5, 3
+    forces_seq = torch.zeros(12, n, b, 3)
+    on = torch.rand(n, b, generator=g) < 0.5
+    for t in range(12):
+        flip = torch.rand(n, b, generator=g) < 0.3
+        on = on ^ flip
+        forces_seq[t, ..., 2] = on * (torch.rand(n, b, generator=g) * 50.0 + 1.5)
+        forces_seq[t, ..., 0] = torch.randn(n, b, generator=g) * 0.3
+    fake = _NS()
+    fake.cfg = _NS(history_length=h, filter_prim_paths_expr=[], track_pose=False, track_air_time=True,
+                   force_threshold=1.0, update_period=0.005)
+    fake._num_envs, fake._num_bodies, fake._sim_physics_dt = n, b, 0.005
+    fake._is_visualizing = False
+    fake._data = _NS(net_forces_w=torch.zeros(n, b, 3), net_forces_w_history=torch.zeros(n, h, b, 3),
+                     last_air_time=torch.zeros(n, b), current_air_time=torch.zeros(n, b),
+                     last_contact_time=torch.zeros(n, b), current_contact_time=torch.zeros(n, b))
+    fake._timestamp = torch.zeros(n)
+    fake._timestamp_last_update = torch.zeros(n)
+    fake._is_outdated = torch.ones(n, dtype=torch.bool)
+    cur = {"t": 0}
+    fake.contact_physx_view = _NS(get_net_contact_forces=lambda dt: forces_seq[cur["t"]].reshape(-1, 3))
+    fake._update_buffers_impl = types.MethodType(cs.ContactSensor._update_buffers_impl, fake)
+    fake._update_outdated_buffers = types.MethodType(sb.SensorBase._update_outdated_buffers, fake)
+    snaps = {k: [] for k in ("hist", "last_air", "cur_air", "last_con", "cur_con", "ts", "first_contact")}
+    for t in range(12):
+        cur["t"] = t
+        sb.SensorBase.update(fake, 0.005)
+        snaps["hist"].append(fake._data.net_forces_w_history.clone())
+        snaps["last_air"].append(fake._data.last_air_time.clone())
+        snaps["cur_air"].append(fake._data.current_air_time.clone())
+        snaps["last_con"].append(fake._data.last_contact_time.clone())
+        snaps["cur_con"].append(fake._data.current_contact_time.clone())
+        snaps["ts"].append(fake._timestamp.clone())
+        fake.data = fake._data
+        snaps["first_contact"].append(cs.ContactSensor.compute_first_contact(fake, 0.02).clone())
+        if t == 6:  # reset two envs mid-sequence (contact_sensor.py:136-155 + sensor_base.py:182-195)
+            ids = [1, 4]
+            sb.SensorBase.reset(fake, ids)
+            fake._data.net_forces_w[ids] = 0.0
+            fake._data.net_forces_w_history[ids] = 0.0
+            for k in ("current_air_time", "last_air_time", "current_contact_time", "last_contact_time"):
+                getattr(fake._data, k)[ids] = 0.0
+    out["contact_forces_seq"] = forces_seq
+    out.update({"contact_" + k: torch.stack(v) for k, v in snaps.items()})
+
+    # ---- ray caster: ray generation of the reference with raycast_mesh intercepted ----
+    cfgp = _NS(resolution=0.1, size=[1.6, 1.0], direction=(0.0, 0.0, -1.0), ordering="xy")
+    starts, dirs = pt.grid_pattern(cfgp, "cpu")
+    out["grid_starts"], out["grid_dirs"] = starts, dirs
+    for yaw_only in (True, False):
+        n = 5
+        fake = _NS()
+        fake.cfg = _NS(attach_yaw_only=yaw_only, max_distance=1e6, mesh_prim_paths=["/World/ground"])
+        pose = torch.zeros(n, 7)
+        pose[:, :3] = torch.randn(n, 3, generator=g)
+        q = rand_quat(g, n)
+        pose[:, 3:] = m.convert_quat(q, to="xyzw")
+
+        class View(rc.physx.ArticulationView if isinstance(rc.physx.ArticulationView, type) else object):
+            pass
+
+        rc.physx.ArticulationView = View
+        view = View.__new__(View)
+        view.get_root_transforms = lambda: pose
+        fake._view = view
+        fake.num_rays = len(dirs)
+        fake.ray_starts = (starts + torch.tensor([0.0, 0.0, 20.0])).repeat(n, 1, 1)
+        fake.ray_directions = dirs.repeat(n, 1, 1)
+        fake.drift = torch.randn(n, 3, generator=g) * 0.01
+        fake._data = _NS(pos_w=torch.zeros(n, 3), quat_w=torch.zeros(n, 4), ray_hits_w=torch.zeros(n, len(dirs), 3))
+        fake.meshes = {"/World/ground": None}
+        captured = {}
+
+        def fake_raycast(ray_starts, ray_directions, max_dist, mesh):
+            captured["starts"], captured["dirs"] = ray_starts.clone(), ray_directions.clone()
+            return (torch.zeros_like(ray_starts), None, None, None)
+
+        rc.raycast_mesh = fake_raycast
+        rc.XFormPrim = type("XFormPrim", (), {})
+        rc.RayCaster._update_buffers_impl(fake, torch.arange(n))
+        tag = "yaw" if yaw_only else "full"
+        out[f"rays_{tag}_pose_xyzw"] = pose
+        out[f"rays_{tag}_drift"] = fake.drift
+        out[f"rays_{tag}_starts_w"] = captured["starts"]
+        out[f"rays_{tag}_dirs_w"] = captured["dirs"]
+        out[f"rays_{tag}_pos_w"], out[f"rays_{tag}_quat_w"] = fake._data.pos_w, fake._data.quat_w
+
+    # ---- ArticulationData derived quantities on a fake physx view ----
+    n, b = 7, 4
+    pose = torch.zeros(n, 7)
+    pose[:, :3] = torch.randn(n, 3, generator=g)
+    pose[:, 3:] = m.convert_quat(rand_quat(g, n), to="xyzw")
+    vel = torch.randn(n, 6, generator=g)
+    lpose = torch.zeros(n, b, 7)
+    lpose[..., :3] = torch.randn(n, b, 3, generator=g)
+    lpose[..., 3:] = m.convert_quat(rand_quat(g, n * b).view(n, b, 4), to="xyzw")
+    lvel = torch.randn(n, b, 6, generator=g)
+    qd_seq = torch.randn(3, n, 6, generator=g)
+    coms = torch.zeros(n, b, 7)
+    coms[..., :3] = torch.randn(n, b, 3, generator=g) * 0.05
+    coms[..., 6] = 1.0
+    cur = {"t": 0}
+    view = _NS(count=n, get_root_transforms=lambda: pose, get_root_velocities=lambda: vel,
+               get_link_transforms=lambda: lpose, get_link_velocities=lambda: lvel,
+               get_dof_positions=lambda: qd_seq[cur["t"]] * 0.1, get_dof_velocities=lambda: qd_seq[cur["t"]],
+               get_coms=lambda: coms, get_link_accelerations=lambda: lvel * 2.0)
+    data = ad.ArticulationData.__new__(ad.ArticulationData)
+    data.device = "cpu"
+    data._root_physx_view = view
+    data._physics_sim_view = _NS(update_articulations_kinematic=lambda: None)
+    data._sim_timestamp = 0.0
+    data.GRAVITY_VEC_W = torch.tensor((0.0, 0.0, -1.0)).repeat(n, 1)
+    data.FORWARD_VEC_B = torch.tensor((1.0, 0.0, 0.0)).repeat(n, 1)
+    from isaaclab.utils.buffers import TimestampedBuffer
+
+    for name in ("_root_state_w", "_root_link_state_w", "_root_com_state_w", "_body_state_w", "_body_link_state_w",
+                 "_body_com_state_w", "_body_acc_w", "_joint_pos", "_joint_acc", "_joint_vel"):
+        setattr(data, name, TimestampedBuffer())
+    data._previous_joint_vel = torch.zeros(n, 6)
+    data._joint_acc.timestamp = 0.0
+    accs = []
+    for t, dt in enumerate((0.005, 0.005, 0.01)):
+        cur["t"] = t
+        data._sim_timestamp += dt
+        accs.append(data.joint_acc.clone())
+    out["ad_pose_xyzw"], out["ad_vel"], out["ad_lpose_xyzw"], out["ad_lvel"] = pose, vel, lpose, lvel
+    out["ad_coms"], out["ad_qd_seq"] = coms, qd_seq
+    out["ad_joint_acc"] = torch.stack(accs)
+    out["ad_root_state_w"] = data.root_state_w
+    out["ad_root_link_state_w"] = data.root_link_state_w
+    out["ad_body_state_w"] = data.body_state_w
+    out["ad_body_link_state_w"] = data.body_link_state_w
+    out["ad_projected_gravity_b"] = data.projected_gravity_b
+    out["ad_heading_w"] = data.heading_w
+    out["ad_root_lin_vel_b"], out["ad_root_ang_vel_b"] = data.root_lin_vel_b, data.root_ang_vel_b
+    save("sensors_state", **out)
+
+
+# ================================================================================================
+def gen_command_action():
+    m = R.ref_math()
+    cmd, ccfg = R.ref_velocity_command()
+    ja = R.load_by_path("_ref_joint_actions", os.path.join(R.LAB, "isaaclab", "envs", "mdp", "actions", "joint_actions.py"))
+    g = torch.Generator().manual_seed(909)
+    out = {}
+    n = 64
+    st = torch.zeros(n, 13)
+    st[:, 3:7] = rand_quat(g, n)
+    st[:, 7:] = torch.randn(n, 6, generator=g)
+    robot = _NS(data=_NS(
+        root_lin_vel_b=m.quat_rotate_inverse(st[:, 3:7], st[:, 7:10]),
+        root_ang_vel_b=m.quat_rotate_inverse(st[:, 3:7], st[:, 10:13]),
+        heading_w=torch.atan2(m.quat_apply(st[:, 3:7], torch.tensor([1.0, 0, 0]).repeat(n, 1))[:, 1],
+                              m.quat_apply(st[:, 3:7], torch.tensor([1.0, 0, 0]).repeat(n, 1))[:, 0])))
+    env = _NS(num_envs=n, device="cpu", step_dt=0.02, scene={"robot": robot})
+    out["root_state"] = st
+    # case A: standard ranges, no resample during compute (time_left large): metrics + heading + standing
+    cfgA = _NS(asset_name="robot", resampling_time_range=(10.0, 10.0), rel_standing_envs=0.02, rel_heading_envs=1.0,
+               heading_command=True, heading_control_stiffness=0.5, debug_vis=False,
+               ranges=_NS(lin_vel_x=(-1.0, 1.0), lin_vel_y=(-1.0, 1.0), ang_vel_z=(-1.0, 1.0), heading=(-math.pi, math.pi)))
+    term = cmd.UniformVelocityCommand.__new__(cmd.UniformVelocityCommand)
+    term.cfg, term._env = cfgA, env
+    term.metrics = {"error_vel_xy": torch.zeros(n), "error_vel_yaw": torch.zeros(n)}
+    term.robot = robot
+    term.time_left = torch.full((n,), 5.0)
+    term.command_counter = torch.zeros(n, dtype=torch.long)
+    term.vel_command_b = torch.randn(n, 3, generator=g)
+    term.heading_target = (torch.rand(n, generator=g) - 0.5) * 6.0
+    term.is_heading_env = torch.rand(n, generator=g) < 0.7
+    term.is_standing_env = torch.rand(n, generator=g) < 0.1
+    out.update({"A_in_cmd": term.vel_command_b.clone(), "A_in_heading_target": term.heading_target.clone(),
+                "A_in_is_heading": term.is_heading_env.clone(), "A_in_is_standing": term.is_standing_env.clone()})
+    term.compute(0.02)
+    term.compute(0.02)
+    out.update({"A_cmd": term.vel_command_b, "A_time_left": term.time_left, "A_m_xy": term.metrics["error_vel_xy"],
+                "A_m_yaw": term.metrics["error_vel_yaw"], "A_counter": term.command_counter})
+    # case B: degenerate ranges -> resampling is RNG-independent; half the envs expire
+    cfgB = _NS(asset_name="robot", resampling_time_range=(10.0, 10.0), rel_standing_envs=0.0, rel_heading_envs=1.0,
+               heading_command=True, heading_control_stiffness=0.5, debug_vis=False,
+               ranges=_NS(lin_vel_x=(0.7, 0.7), lin_vel_y=(-0.3, -0.3), ang_vel_z=(-1.0, 1.0), heading=(0.4, 0.4)))
+    term.cfg = cfgB
+    term.time_left = torch.where(torch.arange(n) % 2 == 0, torch.tensor(0.01), torch.tensor(3.0))
+    term.vel_command_b = torch.randn(n, 3, generator=g)
+    term.is_heading_env = torch.zeros(n, dtype=torch.bool)
+    term.is_standing_env = torch.zeros(n, dtype=torch.bool)
+    term.metrics = {"error_vel_xy": torch.zeros(n), "error_vel_yaw": torch.zeros(n)}
+    out.update({"B_in_cmd": term.vel_command_b.clone(), "B_in_time_left": term.time_left.clone(),
+                "B_in_heading_target": term.heading_target.clone()})
+    term.compute(0.02)
+    out.update({"B_cmd": term.vel_command_b, "B_time_left": term.time_left, "B_counter": term.command_counter,
+                "B_heading_target": term.heading_target, "B_is_heading": term.is_heading_env,
+                "B_is_standing": term.is_standing_env})
+    # joint action processing (joint_actions.py:130-139)
+    raw = torch.randn(n, 12, generator=g)
+    default = torch.randn(n, 12, generator=g) * 0.3
+    out["ja_raw"], out["ja_default"] = raw, default
+    out["ja_processed"] = raw * 0.5 + default
+    save("command_action", **out)
+
+
+# ================================================================================================
+def gen_inhand():
+    ih = R.ref_inhand()
+    m = R.ref_math()
+    g = torch.Generator().manual_seed(1010)
+    out = {}
+    for n in (7, 64):
+        p = f"n{n}_"
+        D, Fg, B, A = 24, 5, 26, 20
+        obj = torch.zeros(n, 13)
+        obj[:, :3] = torch.randn(n, 3, generator=g) * 0.05 + torch.tensor([0.0, -0.39, 0.6])
+        obj[:, 3:7] = rand_quat(g, n)
+        obj[:, 7:] = torch.randn(n, 6, generator=g)
+        origins = torch.randn(n, 3, generator=g) * 3.0
+        obj[:, :3] += origins
+        in_hand = torch.tensor([0.0, -0.39, 0.56]).repeat(n, 1)
+        goal = rand_quat(g, n)
+        goal[::5] = obj[::5, 3:7]  # a few successes
+        obj[1::7, :3] += 0.5  # a few falls
+        actions = torch.rand(n, A, generator=g) * 2 - 1
+        reset_buf = torch.rand(n, generator=g) < 0.2
+        reset_goal = torch.rand(n, generator=g) < 0.1
+        successes = torch.randint(0, 5, (n,), generator=g).float()
+        cons = torch.tensor([1.3])
+        obj_pos = obj[:, :3] - origins
+        rew, goal_resets, succ, cs = ih.compute_rewards(
+            reset_buf, reset_goal, successes, cons, 600.0, obj_pos, obj[:, 3:7], in_hand, goal,
+            -10.0, 1.0, 0.1, actions, -0.0002, 0.1, 250.0, 0.24, 0.0, 0.1)
+        out.update({p + "obj": obj, p + "origins": origins, p + "in_hand": in_hand, p + "goal": goal,
+                    p + "actions": actions, p + "reset_buf": reset_buf, p + "reset_goal": reset_goal,
+                    p + "successes": successes, p + "cons": cons, p + "reward": rew, p + "goal_resets": goal_resets,
+                    p + "successes_out": succ, p + "cons_out": cs})
+        out[p + "rotation_distance"] = ih.rotation_distance(obj[:, 3:7], goal)
+        # apply action
+        lower = -1.0 - torch.rand(n, D, generator=g)
+        upper = 1.0 + torch.rand(n, D, generator=g)
+        act_idx = sorted(torch.randperm(D, generator=g)[:A].tolist())
+        prev = torch.randn(n, D, generator=g) * 0.5
+        cur = torch.zeros(n, D)
+        fake = _NS(cfg=_NS(act_moving_average=0.3), actions=actions, actuated_dof_indices=act_idx,
+                   hand_dof_lower_limits=lower, hand_dof_upper_limits=upper, prev_targets=prev.clone(), cur_targets=cur,
+                   hand=_NS(set_joint_position_target=lambda *a, **k: None))
+        ih.InHandManipulationEnv._apply_action(fake)
+        out.update({p + "lower": lower, p + "upper": upper, p + "act_idx": torch.tensor(act_idx), p + "prev": prev,
+                    p + "cur_out": fake.cur_targets, p + "prev_out": fake.prev_targets})
+        # full observations + dones
+        q = lower + (upper - lower) * torch.rand(n, D, generator=g)
+        qd = torch.randn(n, D, generator=g)
+        body = torch.randn(n, B, 13, generator=g)
+        fingers = sorted(torch.randperm(B, generator=g)[:Fg].tolist())
+        ep = torch.randint(0, 700, (n,), generator=g)
+        fake = _NS(cfg=_NS(vel_obs_scale=0.2, fall_dist=0.24, max_consecutive_success=3, success_tolerance=0.1),
+                   num_envs=n, num_fingertips=Fg, finger_bodies=fingers, actions=actions,
+                   hand=_NS(data=_NS(body_pos_w=body[..., :3].clone(), body_quat_w=body[..., 3:7],
+                                     body_vel_w=body[..., 7:13], joint_pos=q, joint_vel=qd)),
+                   object=_NS(data=_NS(root_pos_w=obj[:, :3], root_quat_w=obj[:, 3:7], root_vel_w=obj[:, 7:13],
+                                       root_lin_vel_w=obj[:, 7:10], root_ang_vel_w=obj[:, 10:13])),
+                   scene=_NS(env_origins=origins), hand_dof_lower_limits=lower, hand_dof_upper_limits=upper,
+                   in_hand_pos=in_hand, goal_rot=goal, successes=successes, episode_length_buf=ep.clone(),
+                   max_episode_length=600)
+        fake._compute_intermediate_values = types.MethodType(ih.InHandManipulationEnv._compute_intermediate_values, fake)
+        oor, to = ih.InHandManipulationEnv._get_dones(fake)
+        obs = ih.InHandManipulationEnv.compute_full_observations(fake)
+        out.update({p + "q": q, p + "qd": qd, p + "body": body, p + "fingers": torch.tensor(fingers), p + "ep": ep,
+                    p + "ep_out": fake.episode_length_buf, p + "out_of_reach": oor, p + "time_out": to,
+                    p + "full_obs": obs})
+    save("inhand", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand"]
+    table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
+             "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand}
+    for w in which:
+        table[w]()
