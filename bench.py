@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Benchmark of the MDP hot path: env-steps/sec of full MDP compute on MI355X.
+
+Workload (the configuration BASELINE.json's metric is quoted on): Isaac-Velocity-Rough-Anymal-C-v0 term set -- 4096
+envs per GPU, 12 joints, 17 contact bodies, decimation 4 (ANYdrive LSTM actuator net + joint_acc + contact sensor per
+substep; `--config anymal_d_rough` swaps in the DC-motor actuator of configs[1]), then terminations,
+11 reward terms, the velocity command generator and the 235-wide observation with the 187-ray height scan cast
+against a ~1.16 M-triangle rough terrain.  Physics state is a synthetic, seeded ring of frames resident in HBM
+(SURVEY.md 8d); one "step" = ManagerBasedRLEnv.step over all envs of the rank.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  Multi-GPU: envs are sharded (fixed 4096 per rank, weak scaling), no data-path
+collective; the episode statistics are merged by one fused RCCL all-reduce per rollout of `--stats-every` steps.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    "anymal_c_rough": "Isaac-Velocity-Rough-Anymal-C-v0 MDP compute (ANYdrive LSTM actuator net, seeded random weights)",
+    "anymal_d_rough": "Isaac-Velocity-Rough-Anymal-D-v0 MDP compute (DC-motor actuator)",
+    "anymal_d_flat": "Isaac-Velocity-Flat-Anymal-D-v0 MDP compute (DC-motor actuator, no height scan)",
+}
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=256)
+    p.add_argument("--warmup", type=int, default=32)
+    p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    p.add_argument("--config", default="anymal_c_rough",
+                   help="anymal_c_rough (BASELINE metric: LSTM actuator net + height scan) | anymal_d_rough | anymal_d_flat")
+    p.add_argument("--ring", type=int, default=32, help="env-steps in the replayed frame ring (x decimation frames)")
+    p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-steps", type=int, default=24)
+    p.add_argument("--stats-every", type=int, default=24, help="rollout length between episode-stat all-reduces")
+    p.add_argument("--small-terrain", action="store_true")
+    return p.parse_args()
+
+
+# ---- algorithmic bytes (SURVEY.md 8d counting rules; table repeated in DESIGN.md) -------------------------
+def algorithmic_bytes(env) -> dict:
+    """Per-env algorithmic HBM bytes of each kernel of one env-step and the launches per env-step."""
+    robot = env.scene["robot"]
+    J = robot.num_joints
+    D = env.cfg.decimation
+    H = 3
+    Bc, Bf = 9, 4                       # bodies referenced by terms (4 feet + 4 thighs + base), feet
+    O = env.observation_manager.group_obs_dim["policy"][0]
+    Tr = sum(1 for c in env.reward_manager._term_cfgs if c.weight != 0.0)
+    Tt = len(env.termination_manager.active_terms)
+    R = env.scene.sensors["height_scanner"].num_rays if "height_scanner" in env.scene.sensors else 0
+    lstm_state_bytes = 0
+    for act in robot.actuators.values():
+        if hasattr(act, "sea_hidden_state"):
+            layers, _, hidden = act.sea_hidden_state.shape
+            lstm_state_bytes = 2 * (2 * layers * hidden) * 4
+    table = {
+        # name: (bytes per env per launch, launches per env-step)
+        # PD family: read target,q,qd; write computed,applied.  LSTM net: + (h, c) of every layer read and written
+        "actuator": (20 * J + lstm_state_bytes * J, D),
+        "joint_acc": (12 * J, D),                              # read qd, RMW prev_qd, write acc
+        "contact_update": (44 * Bc, D),                        # read force, RMW 4 timers (+history shift)
+        "action": (16 * J, 1),                                 # read raw, RMW action/prev_action, write target
+        "termination": (4 * (3 * H * 1 + 2) + Tt + 2, 1),      # base contact history, episode length; flags
+        "reward": (4 * (13 + 4 * J + 3 + 3 * H * Bc + 2 * Bf + J) + 12 * Tr + 4, 1),
+        "command": (4 * 13 + 16 + 12, 1),                      # root state; command RMW; timers
+        "observation": (4 * (13 + 3 * J + 3) + 4 * O + 12 * R + 28, 1),  # state in; obs + ray_hits + sensor pose out
+    }
+    return table
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = f"cuda:{local_rank}"
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device(device))
+    from isaaclab_amd.distributed import EpisodeStats
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+
+    torch.manual_seed(1234 + rank)
+    ring = args.ring
+    env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
+                                 small_terrain=args.small_terrain, inject_random=False)
+    env.observation_manager.persistent_output = True
+    # episode_length_buf ~ U{0..999}
+    g = torch.Generator().manual_seed(99 + rank)
+    env.episode_length_buf.copy_(torch.randint(0, 1000, (args.envs,), generator=g))
+    actions = rec.actions.to(device)
+    stats = EpisodeStats(env, world)
+
+    def eager_steps(k0, count):
+        for k in range(k0, k0 + count):
+            env.step(actions[k % ring])
+
+    # warm-up (also builds the term programs), W untimed steps
+    warm = max(args.warmup, 1)
+    warm = (warm + ring - 1) // ring * ring       # keep the frame cursor aligned with the ring
+    eager_steps(0, warm)
+    torch.cuda.synchronize()
+
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                eager_steps(0, ring)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                eager_steps(0, ring)
+            graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:  # capture is an optimisation; eager launches compute the same thing
+            if rank == 0:
+                print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def run(k_steps):
+        done, next_stats = 0, args.stats_every
+        while done < k_steps:
+            if graph is not None and done + ring <= k_steps:
+                graph.replay()
+                done += ring
+            else:
+                env.step(actions[done % ring])
+                done += 1
+            if done >= next_stats:          # end of a rollout: merge the episode statistics across ranks
+                stats.reduce_async()
+                next_stats += args.stats_every
+        stats.reduce_async()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+
+    K = args.steps
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(K)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    value = world * args.envs * K / elapsed
+
+    out = None
+    if rank == 0:
+        roof = measure_roofline(env, args)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(rec, args)
+        out = {
+            "metric": "env-steps/sec of MDP compute (Anymal-C rough, 4096 envs/GPU) + % HBM peak",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{WORKLOADS[args.config]}: {args.envs} envs/GPU, 12 joints, 17 bodies, decimation 4,"
+                                   f" 187-ray height scan on a {env.mesh.num_tris if hasattr(env, 'mesh') else 0}-triangle terrain,"
+                                   f" ring of {ring * env.cfg.decimation} synthetic state frames",
+                       "envs_per_gpu": args.envs, "hip_graph": graph is not None,
+                       "stats_allreduce_every": args.stats_every},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _time_launches(fn, pre, reps: int) -> float:
+    """Average duration (s) of ``fn`` measured with HIP events on torch's current stream (the launch stream)."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    for i in range(3):
+        pre()
+        fn()
+    torch.cuda.synchronize()
+    for i in range(reps):
+        pre()
+        starts[i].record()
+        fn()
+        stops[i].record()
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    ms = ms[: max(1, int(len(ms) * 0.9))]          # drop the slowest 10 % (scheduler noise)
+    return 1e-3 * sum(ms) / len(ms)
+
+
+def measure_roofline(env, args) -> dict:
+    """Times each kernel of the step in isolation and reports the one with the largest share of the step."""
+    table = algorithmic_bytes(env)
+    N = env.num_envs
+    robot = env.scene["robot"]
+    sensors = env.scene.sensors
+    fns = {
+        "actuator": (lambda: robot.write_data_to_sim(), lambda: None),
+        "contact_update": (lambda: sensors["contact_forces"].update(env.physics_dt), lambda: None),
+        "termination": (lambda: env.termination_manager.compute(), lambda: None),
+        "reward": (lambda: env.reward_manager.compute(dt=env.step_dt), lambda: None),
+        "command": (lambda: env.command_manager.compute(dt=env.step_dt), lambda: None),
+    }
+    if "height_scanner" in sensors:
+        hs = sensors["height_scanner"]
+        # every timed launch must cast: age the sensor by one update period first
+        fns["observation"] = (lambda: env.observation_manager.compute(),
+                              lambda: hs.update(env.step_dt))
+    else:
+        fns["observation"] = (lambda: env.observation_manager.compute(), lambda: None)
+    per_kernel = {}
+    for name, (fn, pre) in fns.items():
+        dur = _time_launches(fn, pre, 60)
+        nbytes, launches = table[name]
+        per_kernel[name] = {"us": 1e6 * dur, "launches_per_step": launches, "alg_bytes_per_env": nbytes,
+                            "GBps": nbytes * N / dur / 1e9}
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["us"] * per_kernel[k]["launches_per_step"])
+    d = per_kernel[dom]
+    total_alg = sum(b * l for b, l in table.values())
+    return {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None,
+            "alg_bytes_per_launch": d["alg_bytes_per_env"] * N, "avg_launch_us": d["us"],
+            "alg_bytes_per_env_step": total_alg, "kernels": per_kernel}
+
+
+def cpu_baseline(rec, args) -> dict:
+    """The numpy + C oracle (a port of the reference algorithm) timed on the host cores, bounded sample."""
+    from oracle.harness import build_oracle, oracle_step
+
+    threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(os.cpu_count() or 1, 16)
+    orc = build_oracle(rec, threads=threads)
+    steps = min(args.cpu_steps, rec.actions.shape[0])
+    oracle_step(orc, rec, 0)                       # warm-up (page-in, OpenMP pool)
+    orc = build_oracle(rec, threads=threads)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        oracle_step(orc, rec, k)
+    dt = time.perf_counter() - t0
+    return {"value": rec.num_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} env-steps x {rec.num_envs} envs of the same workload and frames (numpy oracle; ray cast in C/OpenMP"
+                      f" with {threads} threads, numpy part single-threaded), {dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

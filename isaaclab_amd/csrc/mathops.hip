@@ -170,8 +170,9 @@ __global__ void k_math(int64_t n, MathArgs g) {
 extern "C" int mdp_math_op(int op, int64_t n, const float* a, int lda, const float* b, int ldb, const float* c,
                            int ldc, const float* d, int ldd, float* out, int ldo, int i0, float f0, void* stream) {
     MDP_REQUIRE(op >= 0 && op < MDP_MATH_NUM_OPS, "unknown math op %d", op);
-    MDP_REQUIRE(a && out, "null pointer");
+    MDP_REQUIRE(n >= 0, "negative row count %lld", (long long)n);
     if (n == 0) return MDP_OK;
+    MDP_REQUIRE(a && out, "null pointer");
     MathArgs g{a, lda, b, ldb, c, ldc, d, ldd, out, ldo, i0, f0};
     dim3 grid(grid_for(n, 256)), block(256);
     hipStream_t s = as_stream(stream);

@@ -195,27 +195,37 @@ MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, fl
 }
 
 // ---- BVH (binary, built on the host; stack traversal) -----------------------------------------
+// one axis of the slab test.  A direction component that is exactly 0 constrains nothing as long as the
+// origin lies inside the (closed) slab -- (hi - o) * inv would give 0 or NaN there and cut real hits.
+MDP_RC_FN int mdp_rc_axis(float lo, float hi, float o, float d, float inv, float* tmin, float* tmax) {
+    if (d == 0.0f) {
+        *tmin = -3.0e38f;
+        *tmax = 3.0e38f;
+        return !(o < lo || o > hi);
+    }
+    float a = (lo - o) * inv, b = (hi - o) * inv;
+    *tmin = fminf(a, b);
+    *tmax = fmaxf(a, b);
+    return 1;
+}
+
 MDP_RC_FN int mdp_rc_slab(const float* n, const mdp_ray_t* r, float inv_x, float inv_y, float inv_z, float tmax,
                           float* t_near) {
     // n = {lo.x, lo.y, lo.z, *, hi.x, hi.y, hi.z, *}; conservative (padded by relative eps)
-    float tx0 = (n[0] - r->ox) * inv_x, tx1 = (n[4] - r->ox) * inv_x;
-    float ty0 = (n[1] - r->oy) * inv_y, ty1 = (n[5] - r->oy) * inv_y;
-    float tz0 = (n[2] - r->oz) * inv_z, tz1 = (n[6] - r->oz) * inv_z;
-    float tminx = fminf(tx0, tx1), tmaxx = fmaxf(tx0, tx1);
-    float tminy = fminf(ty0, ty1), tmaxy = fmaxf(ty0, ty1);
-    float tminz = fminf(tz0, tz1), tmaxz = fmaxf(tz0, tz1);
+    float tminx, tmaxx, tminy, tmaxy, tminz, tmaxz;
+    int ok = mdp_rc_axis(n[0], n[4], r->ox, r->dx, inv_x, &tminx, &tmaxx);
+    ok &= mdp_rc_axis(n[1], n[5], r->oy, r->dy, inv_y, &tminy, &tmaxy);
+    ok &= mdp_rc_axis(n[2], n[6], r->oz, r->dz, inv_z, &tminz, &tmaxz);
     float tn = fmaxf(fmaxf(tminx, tminy), fmaxf(tminz, 0.0f));
     float tf = fminf(fminf(tmaxx, tmaxy), fminf(tmaxz, tmax));
     tn -= fabsf(tn) * 1e-5f + 1e-6f;
     tf += fabsf(tf) * 1e-5f + 1e-6f;
     *t_near = tn;
-    return tn <= tf;
+    return ok && tn <= tf;
 }
 
 MDP_RC_FN float mdp_rc_safe_inv(float d) {
-    // direction components that are exactly 0 get a huge finite inverse so the slab test degrades
-    // to an origin-inside check without producing NaN (0 * inf)
-    if (d == 0.0f) return 1.0e30f;
+    if (d == 0.0f) return 0.0f;  // unused for that axis (mdp_rc_axis handles d == 0)
     return 1.0f / d;
 }
 

@@ -1,0 +1,132 @@
+"""Multi-GPU layer of the MDP path: one process per GPU, envs sharded by contiguous
+ranges, NO data-path collective.  The only cross-rank traffic is statistics:
+
+* episode statistics (``Episode_Reward/*``, ``Episode_Termination/*``, ``Metrics/base_velocity/*``;
+  reward_manager.py:115-121, termination_manager.py:142-144, command_manager.py:136-142) travel as ONE packed fp64
+  vector of ``[sum, count]`` pairs through one RCCL all-reduce(sum) per rollout, issued on a side stream so it
+  overlaps the next env steps; means are ``sum(sum) / sum(count)`` (never a mean of means);
+* observation-normaliser moments (my_code/models/my_running_standard_scaler.py:57-80) travel as per-rank
+  ``[n, sum x, M2]`` partials through one all-gather and are merged with the parallel-variance (Chan) formula.
+
+Per-rank partials are produced by the HIP kernels ``mdp_stats_masked_sums`` / ``mdp_stats_moments``; everything
+here is plumbing around ``torch.distributed`` (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests).
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+
+
+def shard_range(num_envs_total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous env-id range ``[lo, hi)`` owned by ``rank`` (remainder spread over the first ranks)."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError(f"bad rank/world {rank}/{world}")
+    base, rem = divmod(num_envs_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def merge_moments(partials: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Chan merge of per-rank ``[n, sum x (D), M2 (D)]`` rows (G, 1 + 2D) fp64 -> (count, mean (D), var (D)).
+
+    ``var`` is the population variance of the union, like ``my_running_standard_scaler.py:69-80``."""
+    p = partials.to(torch.float64)
+    d = (p.shape[1] - 1) // 2
+    n = p[:, 0]
+    total = n.sum()
+    mean = p[:, 1 : 1 + d].sum(dim=0) / total
+    mean_r = p[:, 1 : 1 + d] / n.clamp(min=1.0)[:, None]
+    m2 = (p[:, 1 + d :] + n[:, None] * (mean_r - mean[None, :]) ** 2).sum(dim=0)
+    return total, mean, m2 / total
+
+
+def running_update(mean, var, count, batch_mean, batch_var, batch_count):
+    """my_running_standard_scaler.py:69-80 (parallel-variance update of the running statistics)."""
+    delta = batch_mean - mean
+    total = count + batch_count
+    m2 = var * count + batch_var * batch_count + delta**2 * count * batch_count / total
+    return mean + delta * batch_count / total, m2 / total, total
+
+
+class ObsNormalizerStats:
+    """Running mean/var of the observation, fed by per-rank HIP partials and merged across ranks."""
+
+    def __init__(self, dim: int, device, group=None):
+        self.dim, self.device, self.group = dim, torch.device(device), group
+        self.mean = torch.zeros(dim, dtype=torch.float64, device=self.device)
+        self.var = torch.ones(dim, dtype=torch.float64, device=self.device)
+        self.count = torch.ones((), dtype=torch.float64, device=self.device)
+        self._partial = torch.zeros(1 + 2 * dim, dtype=torch.float64, device=self.device)
+
+    def local_partial(self, obs: torch.Tensor) -> torch.Tensor:
+        obs, ld = L.rows(obs, "obs")
+        L.check(L.lib.mdp_stats_moments(obs.data_ptr(), obs.shape[0], self.dim, ld, self._partial.data_ptr(),
+                                        L.stream(self.device)))
+        return self._partial
+
+    def update(self, obs: torch.Tensor):
+        part = self.local_partial(obs)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            gathered = [torch.empty_like(part) for _ in range(dist.get_world_size(self.group))]
+            dist.all_gather(gathered, part, group=self.group)
+            parts = torch.stack(gathered)
+        else:
+            parts = part[None]
+        n, mean, var = merge_moments(parts)
+        self.mean, self.var, self.count = running_update(self.mean, self.var, self.count, mean, var, n)
+
+
+class EpisodeStats:
+    """Packed ``[sum, count]`` episode statistics with one asynchronous all-reduce per rollout."""
+
+    def __init__(self, env, world_size: int = 1, group=None):
+        self.env, self.world, self.group = env, world_size, group
+        self.device = torch.device(env.device)
+        rm, tm = env.reward_manager, env.termination_manager
+        self.names = ["Episode_Reward/" + n for n in rm.active_terms]
+        self._sources = [(rm._episode_sums_block, len(rm.active_terms))]
+        cmd = env.command_manager.get_term("base_velocity") if "base_velocity" in env.command_manager.active_terms else None
+        if cmd is not None:
+            for k, v in cmd.metrics.items():
+                self.names.append("Metrics/base_velocity/" + k)
+                self._sources.append((v, 1))
+        self._term_block = getattr(tm, "_term_dones_block", None)
+        self.payload = torch.zeros(2 * len(self.names), dtype=torch.float64, device=self.device)
+        self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self._work = None
+        self._ready = torch.cuda.Event() if self._stream is not None else None
+
+    def reduce_async(self, mask: torch.Tensor | None = None):
+        """Per-rank partial sums on a side stream, then one all-reduce(sum) of the packed vector."""
+        cur = torch.cuda.current_stream(self.device)
+        self._ready.record(cur)
+        with torch.cuda.stream(self._stream):
+            self._stream.wait_event(self._ready)
+            off = 0
+            for src, rows in self._sources:
+                L.check(L.lib.mdp_stats_masked_sums(src.data_ptr(), rows, self.env.num_envs, L.ptr(mask),
+                                                    self.payload[off:].data_ptr(), self._stream.cuda_stream))
+                off += 2 * rows
+            if self.world > 1:
+                self._work = dist.all_reduce(self.payload, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def result(self) -> dict[str, float]:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        if self._stream is not None:
+            self._stream.synchronize()
+        return finalize_stats(self.names, self.payload.cpu(), self.env.max_episode_length_s)
+
+
+def finalize_stats(names: list[str], payload: torch.Tensor, max_episode_length_s: float) -> dict[str, float]:
+    """``sum(sum)/sum(count)``; episodic reward sums are divided by the episode length in seconds like
+    reward_manager.py:119."""
+    out = {}
+    for i, name in enumerate(names):
+        s, c = float(payload[2 * i]), float(payload[2 * i + 1])
+        mean = s / c if c > 0 else 0.0
+        out[name] = mean / max_episode_length_s if name.startswith("Episode_Reward/") else mean
+    return out

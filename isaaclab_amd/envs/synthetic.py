@@ -75,3 +75,124 @@ def generate_frames(view: SyntheticPhysicsView, num_frames: int, seed: int, env_
 def generate_actions(num_steps: int, num_envs: int, action_dim: int, seed: int) -> torch.Tensor:
     rng = np.random.RandomState(seed + 7919)
     return torch.from_numpy(np.clip(rng.normal(0, 1, size=(num_steps, num_envs, action_dim)), -3, 3).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Replay harness (SURVEY.md section 8c "MdpStepHarness"): env over a pre-generated ring of physics frames
+# ---------------------------------------------------------------------------------------------------------
+class Recording:
+    """Pure data describing one synthetic run: everything a CPU checker needs to redo the same steps."""
+
+    def __init__(self):
+        self.name = ""
+        self.num_envs = 0
+        self.decimation = 4
+        self.frames: torch.Tensor | None = None      # host (1 + steps * decimation, frame_size); frame 0 = initial state
+        self.fields: dict[str, tuple[int, int, tuple]] = {}
+        self.actions: torch.Tensor | None = None     # host (steps, N, A)
+        self.env_origins: np.ndarray | None = None
+        self.vertices: np.ndarray | None = None      # terrain mesh (None for the flat configs)
+        self.triangles: np.ndarray | None = None
+        self.cmd_uniforms: torch.Tensor | None = None  # host (steps, N, 7) or None (device generator)
+        self.obs_noise: dict[str, torch.Tensor] = {}   # term name -> host (steps, N, dim) uniforms in [0, 1)
+        self.network = None                           # actuator net module (anymal_c_rough)
+        self._dev_noise: dict[str, torch.Tensor] = {}
+        self._dev_cmd: torch.Tensor | None = None
+
+    def field(self, name: str, t: int) -> np.ndarray:
+        o, s, shape = self.fields[name]
+        return self.frames[t, o : o + s].view(shape).numpy()
+
+    def feed(self, t: int):
+        """Copies the injected random numbers of env-step ``t`` into the device tensors the kernels read."""
+        for name, dev in self._dev_noise.items():
+            dev.copy_(self.obs_noise[name][t], non_blocking=True)
+        if self._dev_cmd is not None:
+            self._dev_cmd.copy_(self.cmd_uniforms[t], non_blocking=True)
+
+
+def synthetic_anydrive_lstm(seed: int = 303, hidden: int = 8, layers: int = 2):
+    """Stand-in for ``anydrive_3_lstm_jit.pt`` (remote in the reference, ASSETS/robots/anymal.py:47): a module with the
+    attributes the actuator inspects (``.lstm`` state dict, actuator_net.py:53-54) -- LSTM(2 -> hidden, layers) +
+    Linear(hidden -> 1), seeded random weights."""
+
+    class SeaNet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lstm = torch.nn.LSTM(2, hidden, layers, batch_first=True)
+            self.decoder = torch.nn.Sequential(torch.nn.Linear(hidden, 1))
+
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    net = SeaNet()
+    torch.random.set_rng_state(gen_state)
+    return net
+
+
+def _env_cfg(name: str, num_envs: int, network=None):
+    from ..tasks.velocity.config import anymal, h1
+
+    if name == "anymal_d_flat":
+        cfg = anymal.AnymalDFlatEnvCfg()
+    elif name == "anymal_d_rough":
+        cfg = anymal.AnymalDRoughEnvCfg()
+    elif name == "anymal_c_rough":
+        cfg = anymal.AnymalCRoughEnvCfg(network_file=network)
+    elif name == "h1_rough":
+        cfg = h1.H1RoughEnvCfg()
+    else:
+        raise ValueError(f"unknown velocity config '{name}' (anymal_d_flat | anymal_d_rough | anymal_c_rough | h1_rough)")
+    cfg.scene.num_envs = num_envs
+    return cfg
+
+
+def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: int = 8, seed: int = 0,
+                      small_terrain: bool = False, inject_random: bool = True, network=None, terrain=None):
+    """Builds a velocity-task env over a replayed synthetic physics feed.  Returns ``(env, recording)``.
+
+    ``inject_random=True`` replaces the device generators of the command term and of the observation noise by
+    recorded uniforms (parity tests); ``False`` leaves the device-side Philox generators on (benchmark)."""
+    from ..terrains import SyntheticTerrain, SyntheticTerrainCfg
+    from ..terrains.synthetic import TerrainGeneratorCfg
+    from .manager_based_rl_env import ManagerBasedRLEnv
+
+    if name == "anymal_c_rough" and network is None:
+        network = synthetic_anydrive_lstm()
+    cfg = _env_cfg(name, num_envs, network)
+    rough = cfg.scene.height_scanner is not None
+    if terrain is None and rough:
+        gen = TerrainGeneratorCfg(num_rows=2, num_cols=5) if small_terrain else TerrainGeneratorCfg()
+        terrain = SyntheticTerrain(SyntheticTerrainCfg(terrain_generator=gen, max_init_terrain_level=1 if small_terrain else 5),
+                                   num_envs)
+    env = ManagerBasedRLEnv(cfg, device=device, terrain=terrain if rough else None)
+    view = env.physics
+    robot = env.scene["robot"]
+    rec = Recording()
+    rec.name, rec.num_envs, rec.decimation, rec.network = name, num_envs, cfg.decimation, network
+    rec.env_origins = env.scene.env_origins.cpu().numpy()
+    if rough:
+        rec.vertices, rec.triangles = terrain.vertices, terrain.triangles
+    rec.fields = {k: (o, s, tuple(view._shapes[k])) for k, (o, s) in view._slices.items()}
+    nframes = 1 + steps * cfg.decimation
+    rec.frames = generate_frames(view, nframes, seed, rec.env_origins, robot.data.default_joint_pos[0].cpu().numpy(),
+                                 robot.body_names, with_links=True)
+    rec.actions = generate_actions(steps, num_envs, env.action_manager.total_action_dim, seed)
+    view.live.copy_(rec.frames[0])
+    view.set_frames(rec.frames[1:])
+    if inject_random:
+        rng = np.random.RandomState(seed + 104729)
+        rec.cmd_uniforms = torch.from_numpy(rng.uniform(size=(steps, num_envs, 7)).astype(np.float32))
+        term = env.command_manager.get_term("base_velocity")
+        rec._dev_cmd = torch.zeros((num_envs, 7), dtype=torch.float32, device=device)
+        term.injected_uniforms = rec._dev_cmd
+        om = env.observation_manager
+        for tname, tcfg, dims in zip(om.active_terms["policy"], om._group_obs_term_cfgs["policy"],
+                                     om.group_obs_term_dim["policy"]):
+            if tcfg.noise is None:
+                continue
+            dim = int(np.prod(dims))
+            rec.obs_noise[tname] = torch.from_numpy(rng.uniform(size=(steps, num_envs, dim)).astype(np.float32))
+            dev = torch.zeros((num_envs, dim), dtype=torch.float32, device=device)
+            tcfg._injected_noise = dev
+            rec._dev_noise[tname] = dev
+    return env, rec

@@ -32,6 +32,9 @@ def _collect_annotations(cls):
     for name, value in list(cls.__dict__.items()):
         if name.startswith("__") or name in ann:
             continue
+        if name in merged and not isinstance(value, (classmethod, staticmethod, property)):
+            ann[name] = merged[name]  # new default for an inherited field (e.g. ``func = uniform_noise``)
+            continue
         if isinstance(value, (classmethod, staticmethod, property)) or inspect.isfunction(value):
             continue
         if isinstance(value, type) and name[:1].isupper():

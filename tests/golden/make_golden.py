@@ -723,8 +723,10 @@ def gen_sensors_state():
     coms[..., :3] = torch.randn(n, b, 3, generator=g) * 0.05
     coms[..., 6] = 1.0
     cur = {"t": 0}
-    view = _NS(count=n, get_root_transforms=lambda: pose, get_root_velocities=lambda: vel,
-               get_link_transforms=lambda: lpose, get_link_velocities=lambda: lvel,
+    # PhysX fills its buffer afresh on every getter call; the reference edits the returned tensor in place
+    # (articulation_data.py:360-365), so the fake view hands out copies
+    view = _NS(count=n, get_root_transforms=lambda: pose.clone(), get_root_velocities=lambda: vel.clone(),
+               get_link_transforms=lambda: lpose.clone(), get_link_velocities=lambda: lvel.clone(),
                get_dof_positions=lambda: qd_seq[cur["t"]] * 0.1, get_dof_velocities=lambda: qd_seq[cur["t"]],
                get_coms=lambda: coms, get_link_accelerations=lambda: lvel * 2.0)
     data = ad.ArticulationData.__new__(ad.ArticulationData)
@@ -795,8 +797,9 @@ def gen_command_action():
                 "A_in_is_heading": term.is_heading_env.clone(), "A_in_is_standing": term.is_standing_env.clone()})
     term.compute(0.02)
     term.compute(0.02)
-    out.update({"A_cmd": term.vel_command_b, "A_time_left": term.time_left, "A_m_xy": term.metrics["error_vel_xy"],
-                "A_m_yaw": term.metrics["error_vel_yaw"], "A_counter": term.command_counter})
+    out.update({"A_cmd": term.vel_command_b.clone(), "A_time_left": term.time_left.clone(),
+                "A_m_xy": term.metrics["error_vel_xy"].clone(), "A_m_yaw": term.metrics["error_vel_yaw"].clone(),
+                "A_counter": term.command_counter.clone()})
     # case B: degenerate ranges -> resampling is RNG-independent; half the envs expire
     cfgB = _NS(asset_name="robot", resampling_time_range=(10.0, 10.0), rel_standing_envs=0.0, rel_heading_envs=1.0,
                heading_command=True, heading_control_stiffness=0.5, debug_vis=False,

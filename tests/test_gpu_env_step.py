@@ -1,0 +1,94 @@
+"""GPU: full MDP env-step (ManagerBasedRLEnv.step order) of the velocity task over a replayed synthetic
+physics feed, HIP path vs the CPU oracle on the same seeded frames / actions / injected random numbers.
+Bit-exact: terminated / time_outs masks.  fp32: 1e-5 relative (1e-5 absolute floor on observations whose
+terms cancel, 2e-6 on rewards)."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def run_env(name, n, steps, device, seed, **kw):
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+
+    env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=seed, **kw)
+    outs = []
+    for t in range(steps):
+        rec.feed(t)
+        obs, rew, term, trunc, _ = env.step(rec.actions[t].to(device))
+        outs.append((to_np(obs["policy"]), to_np(rew), to_np(term), to_np(trunc)))
+    torch.cuda.synchronize()
+    return env, rec, outs
+
+
+def compare(outs, ref):
+    for t, (got, exp) in enumerate(zip(outs, ref)):
+        assert_close(got[2], exp[2], msg=f"terminated step {t}")
+        assert_close(got[3], exp[3], msg=f"time_outs step {t}")
+        assert_close(got[1], exp[1], rtol=1e-5, atol=2e-6, msg=f"reward step {t}")
+        assert_close(got[0], exp[0], rtol=1e-5, atol=1e-5, msg=f"obs step {t}")
+
+
+@pytest.mark.parametrize("n", (7, 256))
+def test_anymal_d_flat(device, n):
+    """BASELINE config C1 (flat, DC motor, 48-dim observation)."""
+    from oracle.harness import replay_oracle
+
+    env, rec, outs = run_env("anymal_d_flat", n, 6, device, seed=11)
+    assert outs[0][0].shape == (n, 48)
+    compare(outs, replay_oracle(rec, 6))
+
+
+@pytest.mark.parametrize("n", (5, 128))
+def test_anymal_d_rough(device, n):
+    """BASELINE config C2 (rough, 187-ray height scan fused into the observation kernel, 235-dim observation)."""
+    from oracle.harness import replay_oracle
+
+    env, rec, outs = run_env("anymal_d_rough", n, 6, device, seed=12, small_terrain=True)
+    assert outs[0][0].shape == (n, 235)
+    compare(outs, replay_oracle(rec, 6))
+    # sensor state after the run.  The rays themselves come from quat_apply_yaw on device vs host libm (1-ulp
+    # differences in the ray origins), so hits agree to fp32 tolerance here; bit-exactness of the caster on
+    # identical rays is tests/test_raycast.py.
+    from oracle.harness import build_oracle, oracle_step
+
+    orc = build_oracle(rec)
+    for k in range(6):
+        oracle_step(orc, rec, k)
+    hits = to_np(env.scene["height_scanner"].data.ray_hits_w)
+    assert_close(hits, orc.ray_hits, rtol=1e-5, atol=1e-5)
+
+
+def test_episode_sums_and_logs(device):
+    from oracle.harness import build_oracle, oracle_step
+
+    env, rec, outs = run_env("anymal_d_flat", 64, 5, device, seed=13)
+    orc = build_oracle(rec)
+    for k in range(5):
+        oracle_step(orc, rec, k)
+    rm = env.reward_manager
+    sums = np.stack([to_np(rm._episode_sums[name]) for name in rm.active_terms])
+    assert_close(sums, orc.episode_sums, rtol=1e-5, atol=2e-6)
+    assert_close(to_np(env.termination_manager.get_term("base_contact")), orc.term_dones[1])
+    cmd = env.command_manager.get_term("base_velocity")
+    assert_close(to_np(cmd.command), orc.command.cmd, rtol=1e-5, atol=1e-6)
+    assert_close(to_np(cmd.time_left), orc.command.time_left, rtol=1e-5, atol=1e-6)
+    assert_close(to_np(cmd.metrics["error_vel_xy"]), orc.command.m_xy, rtol=1e-5, atol=1e-6)
+
+
+def test_anymal_c_rough_lstm(device):
+    """BASELINE metric configuration: rough terrain + ANYdrive LSTM actuator net (seeded random weights)."""
+    from oracle.harness import replay_oracle
+
+    env, rec, outs = run_env("anymal_c_rough", 96, 5, device, seed=14, small_terrain=True)
+    assert outs[0][0].shape == (96, 235)
+    ref = replay_oracle(rec, 5)
+    # the MFMA LSTM sums in a different order than numpy: torques agree to ~1e-5 abs, which the
+    # dof_torques_l2 reward (weight 1e-5) damps far below the reward tolerance
+    compare(outs, ref)
+    act = env.scene["robot"].actuators["legs"]
+    assert act.sea_hidden_state.abs().max().item() > 0.0
