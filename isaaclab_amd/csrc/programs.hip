@@ -32,6 +32,8 @@ struct mdp_program {
     int total_cols = 0;
     int uses_rng = 0;
     int has_cast = 0;
+    int cast_ti = -1;  // first fused ray-cast term (its sensor pose is staged in LDS)
+    RayAux h_cast{};   // host copy of that term's descriptor (passed to k_obs by value)
     std::vector<mdp_term_t> h_terms;
 };
 
@@ -115,18 +117,32 @@ MDP_DEV float obs_value(const mdp_term_t& t, const int32_t* __restrict__ pool, i
     }
 }
 
-MDP_DEV float obs_height_scan_cast(const mdp_term_t& t, int e, int k, bool od) {
-    const RayAux* a = (const RayAux*)t.p4;
+// sensor pose of one env for the fused cast (ray_caster.py:226-252): position (+ drift) and the rotation
+// applied to the ray pattern (yaw-only or full).  Computed once per env and shared through LDS.
+MDP_DEV void cast_pose(const mdp_raycaster_desc_t& d, int e, V3* pos, Q4* qr, Q4* q) {
+    const float* p = d.root_pose + (int64_t)e * d.ld_pose;
+    *pos = ld3(p);
+    if (d.drift) { pos->x += d.drift[3 * e]; pos->y += d.drift[3 * e + 1]; pos->z += d.drift[3 * e + 2]; }
+    *q = ld4(p + 3);
+    *qr = d.attach_yaw_only ? yaw_quat(*q) : *q;
+}
+
+MDP_DEV float obs_height_scan_cast(const RayAux& aux, float offset, int e, int k, bool od, const float* pose) {
+    const RayAux* a = &aux;
     const mdp_raycaster_desc_t& d = a->d;
     const float inf = __builtin_inff();
     int R = d.num_rays;
     float* o = d.ray_hits_w + ((int64_t)e * R + k) * 3;
-    if (!od) return (d.pos_w[3 * (int64_t)e + 2] - o[2]) - t.f0;
-    const float* p = d.root_pose + (int64_t)e * d.ld_pose;
-    V3 pos = ld3(p);
-    if (d.drift) { pos.x += d.drift[3 * e]; pos.y += d.drift[3 * e + 1]; pos.z += d.drift[3 * e + 2]; }
-    Q4 q = ld4(p + 3);
-    Q4 qr = d.attach_yaw_only ? yaw_quat(q) : q;
+    if (!od) return (d.pos_w[3 * (int64_t)e + 2] - o[2]) - offset;
+    V3 pos;
+    Q4 qr, q;
+    if (pose) {
+        pos = V3{pose[0], pose[1], pose[2]};
+        qr = Q4{pose[3], pose[4], pose[5], pose[6]};
+        q = qr;  // only read when the full rotation is attached, in which case qr == q
+    } else {
+        cast_pose(d, e, &pos, &qr, &q);
+    }
     V3 s = quat_apply(qr, ld3(d.ray_starts_local + 3 * k));
     s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
     V3 dir = ld3(d.ray_dirs_local + 3 * k);
@@ -139,7 +155,7 @@ MDP_DEV float obs_height_scan_cast(const mdp_term_t& t, int e, int k, bool od) {
     } else {
         o[0] = inf; o[1] = inf; o[2] = inf; hz = inf;
     }
-    return (pos.z - hz) - t.f0;
+    return (pos.z - hz) - offset;
 }
 
 MDP_DEV void obs_cast_commit(const mdp_term_t& t, int e) {
@@ -180,16 +196,49 @@ MDP_DEV float obs_post(const mdp_term_t& t, float v, int e, int k, uint64_t seed
     return v;
 }
 
-__global__ void k_obs(const mdp_term_t* __restrict__ terms, int T, const int32_t* __restrict__ pool,
-                      const int16_t* __restrict__ col2term, int O, int N, int epb, int slot_w,
-                      float* __restrict__ obs, int ld_obs, uint64_t* rng, int uses_rng, int has_cast) {
+constexpr int OBS_POSE_SLOTS = 32;  // env slots per block whose sensor pose is staged in LDS
+
+// Every lane of a wave walks a different column, so term records would be fetched with per-lane (vector) global
+// loads, one dependent round trip per field.  The block stages the term table and the column map in LDS
+// once; the descriptor of the fused ray-cast term arrives by value (scalar registers).
+__global__ void k_obs(const mdp_term_t* __restrict__ g_terms, int T, const int32_t* __restrict__ pool,
+                      const int16_t* __restrict__ g_col2term, int O, int N, int epb, int slot_w,
+                      float* __restrict__ obs, int ld_obs, uint64_t* rng, int uses_rng, int has_cast, int cast_ti,
+                      RayAux cast) {
+    __shared__ float s_pose[OBS_POSE_SLOTS][8];
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    mdp_term_t* terms = reinterpret_cast<mdp_term_t*>(s_dyn);
+    int16_t* col2term = reinterpret_cast<int16_t*>(s_dyn + (size_t)T * sizeof(mdp_term_t));
+    {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(g_terms);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(s_dyn);
+        const int words = T * (int)(sizeof(mdp_term_t) / 4);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < O; i += blockDim.x) col2term[i] = g_col2term[i];
+    }
+    __syncthreads();
     int le = threadIdx.x / slot_w;
     int lc = threadIdx.x - le * slot_w;
     uint64_t seed = 0, epoch = 0;
     if (uses_rng) { seed = rng[0]; epoch = rng[1]; }
+    const bool stage_pose = has_cast && cast_ti >= 0 && epb <= OBS_POSE_SLOTS;
     for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
         int e = base + le;
         bool active = le < epb && e < N;
+        if (stage_pose) {
+            if (active && lc == 0) {
+                bool od = cast.d.is_outdated ? (cast.d.is_outdated[e] != 0) : true;
+                s_pose[le][7] = od ? 1.0f : 0.0f;
+                if (od) {
+                    V3 pos;
+                    Q4 qr, q;
+                    cast_pose(cast.d, e, &pos, &qr, &q);
+                    s_pose[le][0] = pos.x; s_pose[le][1] = pos.y; s_pose[le][2] = pos.z;
+                    s_pose[le][3] = qr.w; s_pose[le][4] = qr.x; s_pose[le][5] = qr.y; s_pose[le][6] = qr.z;
+                }
+            }
+            __syncthreads();
+        }
         if (active) {
             for (int c = lc; c < O; c += slot_w) {
                 int ti = col2term[c];
@@ -197,9 +246,13 @@ __global__ void k_obs(const mdp_term_t* __restrict__ terms, int T, const int32_t
                 int k = c - t.out_offset;
                 float v;
                 if (t.op == MDP_OBS_HEIGHT_SCAN_CAST) {
-                    const RayAux* a = (const RayAux*)t.p4;
-                    bool od = a->d.is_outdated ? (a->d.is_outdated[e] != 0) : true;
-                    v = obs_height_scan_cast(t, e, k, od);
+                    if (stage_pose && ti == cast_ti) {
+                        v = obs_height_scan_cast(cast, t.f0, e, k, s_pose[le][7] != 0.0f, s_pose[le]);
+                    } else {
+                        const RayAux* a = (const RayAux*)t.p4;
+                        bool od = a->d.is_outdated ? (a->d.is_outdated[e] != 0) : true;
+                        v = obs_height_scan_cast(*a, t.f0, e, k, od, nullptr);
+                    }
                 } else {
                     v = obs_value(t, pool, e, k);
                 }
@@ -610,6 +663,7 @@ extern "C" int mdp_program_create(int kind, int device, int num_envs, const mdp_
                 a.d = *d;
                 a.d.mesh = nullptr;
                 aux.push_back(a);
+                if (!p->has_cast) { p->cast_ti = i; p->h_cast = a; }
                 p->has_cast = 1;
             }
         } else {
@@ -670,9 +724,11 @@ extern "C" int mdp_obs_compute(mdp_program_t* p, float* obs, int ld_obs, void* s
     int slot_w = O >= 256 ? 256 : O;
     int threads = ((epb * slot_w + 63) / 64) * 64;
     int64_t blocks = ((int64_t)p->num_envs + epb - 1) / epb;
-    hipLaunchKernelGGL(k_obs, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0, as_stream(stream), p->d_terms,
+    size_t lds = (size_t)p->num_terms * sizeof(mdp_term_t) + (size_t)O * sizeof(int16_t);
+    if (lds > 48 * 1024) return fail(MDP_ERR_UNSUPPORTED, "observation program too large for the LDS term table (%zu B)", lds);
+    hipLaunchKernelGGL(k_obs, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), lds, as_stream(stream), p->d_terms,
                        p->num_terms, p->d_pool, p->d_col2term, O, p->num_envs, epb, slot_w, obs, ld_obs, p->d_rng,
-                       p->uses_rng, p->has_cast);
+                       p->uses_rng, p->has_cast, p->cast_ti, p->h_cast);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

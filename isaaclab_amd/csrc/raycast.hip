@@ -163,11 +163,43 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
             }
         }
     // ---- uniform xy grid
+    // cell edge = median triangle footprint size sqrt(2 * area_xy): on a height field (the common case) that is the
+    // lattice pitch, so with the half-cell offset below every cell overlaps ~6 triangles.  A size derived from
+    // the mesh extent would be skewed by empty borders and by a few huge triangles (stairs, slabs).
     double ex = (double)mx[0] - mn[0], ey = (double)mx[1] - mn[1];
-    double area = std::max(ex, 1e-6) * std::max(ey, 1e-6);
-    double cell = std::sqrt(2.0 * area / (double)num_tris);
-    const double max_cells = 8.0e6;
-    if ((ex / cell + 2) * (ey / cell + 2) > max_cells) cell = std::sqrt((ex + 1e-6) * (ey + 1e-6) / (max_cells * 0.9));
+    double cell;
+    {
+        std::vector<float> sizes;
+        sizes.reserve((size_t)num_tris);
+        for (int f = 0; f < num_tris; ++f) {
+            const float* t = tv.data() + 9 * (size_t)f;
+            double a2 = std::fabs(((double)t[3] - t[0]) * ((double)t[7] - t[1]) - ((double)t[6] - t[0]) * ((double)t[4] - t[1]));
+            if (a2 > 0.0) sizes.push_back((float)std::sqrt(a2));   // a2 = 2 * area_xy
+        }
+        if (sizes.empty()) {
+            cell = std::sqrt(std::max(ex, 1e-6) * std::max(ey, 1e-6));
+        } else {
+            std::nth_element(sizes.begin(), sizes.begin() + sizes.size() / 2, sizes.end());
+            cell = sizes[sizes.size() / 2];
+        }
+        cell = std::max(cell, 1e-4);
+    }
+    // memory guards: at most 8 M cells and (bounding-box estimate) 48 M cell references (48 B each)
+    const double max_cells = 8.0e6, max_refs = 48.0e6;
+    for (int guard = 0; guard < 64; ++guard) {
+        double cells = (ex / cell + 2) * (ey / cell + 2);
+        double refs = 0.0;
+        if (cells <= max_cells) {
+            for (int f = 0; f < num_tris; ++f) {
+                const float* t = tv.data() + 9 * (size_t)f;
+                double wx = std::max(t[0], std::max(t[3], t[6])) - std::min(t[0], std::min(t[3], t[6]));
+                double wy = std::max(t[1], std::max(t[4], t[7])) - std::min(t[1], std::min(t[4], t[7]));
+                refs += 0.5 * (wx / cell + 1.0) * (wy / cell + 1.0) + 1.0;
+            }
+        }
+        if (cells <= max_cells && refs <= max_refs) break;
+        cell *= 1.25;
+    }
     if (!(cell > 0)) cell = 1.0;
     // half-cell offset keeps lattice-aligned height-field edges away from cell borders
     float gx0 = (float)(mn[0] - 0.5 * cell), gy0 = (float)(mn[1] - 0.5 * cell);
@@ -212,6 +244,33 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
                 }
         }
     }
+    // ---- cell records: per cell sorted by descending zmax (ties: ascending face id), 12 floats each
+    std::vector<float> recs;
+    {
+        const size_t ncell = (size_t)ncx * ncy;
+        std::vector<float> zmax_of((size_t)num_tris), zmin_of((size_t)num_tris);
+        for (int f = 0; f < num_tris; ++f) {
+            const float* t = tv.data() + 9 * (size_t)f;
+            zmax_of[f] = std::max(t[2], std::max(t[5], t[8]));
+            zmin_of[f] = std::min(t[2], std::min(t[5], t[8]));
+        }
+        for (size_t c = 0; c < ncell; ++c) {
+            auto b = m->h_cell_tris.begin() + counts[c], e = m->h_cell_tris.begin() + counts[c + 1];
+            if (e - b > 1)
+                std::sort(b, e, [&](int32_t x, int32_t y) {
+                    return zmax_of[x] > zmax_of[y] || (zmax_of[x] == zmax_of[y] && x < y);
+                });
+        }
+        recs.resize(m->h_cell_tris.size() * 12);
+        for (size_t k = 0; k < m->h_cell_tris.size(); ++k) {
+            int32_t f = m->h_cell_tris[k];
+            float* r = recs.data() + 12 * k;
+            std::memcpy(r, tv.data() + 9 * (size_t)f, 9 * sizeof(float));
+            std::memcpy(r + 9, &f, sizeof(int32_t));
+            r[10] = zmax_of[f];
+            r[11] = zmin_of[f];
+        }
+    }
     // ---- BVH
     BvhBuilder bb;
     bb.tv = tv.data();
@@ -240,7 +299,8 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     int64_t bytes = 0;
     int rc;
     float* d_tv = nullptr; int32_t* d_cs = nullptr; int32_t* d_ct = nullptr; float* d_nodes = nullptr; int32_t* d_bt = nullptr;
-    if ((rc = upload(tv, &d_tv, &bytes)) || (rc = upload(counts, &d_cs, &bytes)) ||
+    float* d_recs = nullptr;
+    if ((rc = upload(tv, &d_tv, &bytes)) || (rc = upload(counts, &d_cs, &bytes)) || (rc = upload(recs, &d_recs, &bytes)) ||
         (rc = upload(m->h_cell_tris, &d_ct, &bytes)) || (rc = upload(bb.nodes, &d_nodes, &bytes)) ||
         (rc = upload(bb.order, &d_bt, &bytes))) {
         delete m;
@@ -255,6 +315,7 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     v.num_tris = num_tris;
     v.cell_start = d_cs;
     v.cell_tris = d_ct;
+    v.cell_recs = d_recs;
     v.gx0 = gx0; v.gy0 = gy0; v.cell = cellf; v.inv_cell = 1.0f / cellf;
     v.ncx = ncx; v.ncy = ncy;
     v.zmin = mn[2]; v.zmax = mx[2];
@@ -278,6 +339,7 @@ extern "C" int mdp_mesh_destroy(mdp_mesh_t* mesh) {
     (void)hipFree((void*)mesh->view.tri_verts);
     (void)hipFree((void*)mesh->view.cell_start);
     (void)hipFree((void*)mesh->view.cell_tris);
+    (void)hipFree((void*)mesh->view.cell_recs);
     (void)hipFree((void*)mesh->view.bvh_nodes);
     (void)hipFree((void*)mesh->view.bvh_tris);
     delete mesh;

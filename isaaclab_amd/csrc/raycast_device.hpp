@@ -36,6 +36,11 @@ typedef struct {
     const int32_t* bvh_tris;  // leaf triangle ids
     int32_t num_nodes;
     int32_t accel;  // 1 grid, 2 bvh
+    // optional cell-ordered triangle records (device builder): one 48-byte record per cell reference, stored
+    // in cell order, within a cell by descending zmax: {a.xyz, b.xyz, c.xyz, face id (int bits), zmax, zmin}.
+    // A ray reads ONE contiguous run per visited cell instead of chasing cell_tris -> tri_verts, and a
+    // downward ray stops at the first record that lies entirely below its current best hit.
+    const float* cell_recs;
 } mdp_mesh_view_t;
 
 typedef struct {
@@ -125,6 +130,66 @@ MDP_RC_FN void mdp_rc_consider(const mdp_ray_t* r, const float* tri_verts, int32
     }
 }
 
+// 12-float cell record (vertices, face id, zmax, zmin)
+typedef struct { float v[12]; } mdp_rec_t;
+
+MDP_RC_FN mdp_rec_t mdp_rc_load_rec(const float* rec) {
+    mdp_rec_t o;
+#ifdef MDP_RC_HOST
+    for (int i = 0; i < 12; ++i) o.v[i] = rec[i];
+#else
+    const float4* q = (const float4*)rec;  // records are 16-byte aligned: three 128-bit loads
+    float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    o.v[0] = q0.x; o.v[1] = q0.y; o.v[2] = q0.z; o.v[3] = q0.w;
+    o.v[4] = q1.x; o.v[5] = q1.y; o.v[6] = q1.z; o.v[7] = q1.w;
+    o.v[8] = q2.x; o.v[9] = q2.y; o.v[10] = q2.z; o.v[11] = q2.w;
+#endif
+    return o;
+}
+
+MDP_RC_FN int32_t mdp_rc_rec_face(const mdp_rec_t* rec) {
+    union { float f; int32_t i; } u;
+    u.f = rec->v[9];
+    return u.i;
+}
+
+// same as mdp_rc_consider for a cell record
+MDP_RC_FN void mdp_rc_consider_rec(const mdp_ray_t* r, const mdp_rec_t* rec, mdp_hit_t* best) {
+    int32_t f = mdp_rc_rec_face(rec);
+    float t, u, v;
+    if (mdp_rc_intersect(r, rec->v, &t, &u, &v)) {
+        if (t >= 0.0f && (t < best->t || (t == best->t && f < best->face && best->face >= 0))) {
+            best->t = t;
+            best->face = f;
+        }
+    }
+}
+
+// All records of one cell.  Loads are issued four records at a time (independent of the running best hit)
+// so a lane has 12 x 128-bit loads in flight instead of one dependent round trip per triangle.
+MDP_RC_FN void mdp_rc_cell_recs(const mdp_mesh_view_t* m, const mdp_ray_t* r, int32_t b, int32_t e, mdp_hit_t* best) {
+    // records are sorted by descending zmax: on a downward ray a triangle lying entirely below the current best
+    // hit needs a strictly larger t, and so does every record after it
+    const int down = r->dz < 0.0f;
+    const float inv_dz = down ? 1.0f / r->dz : 0.0f;
+    int stop = 0;
+    for (int32_t k = b; k < e && !stop; k += 4) {
+        mdp_rec_t R[4];
+        for (int i = 0; i < 4; ++i) {
+            int32_t kk = k + i < e ? k + i : e - 1;
+            R[i] = mdp_rc_load_rec(m->cell_recs + 12 * (int64_t)kk);
+        }
+        for (int i = 0; i < 4; ++i) {
+            if (k + i >= e || stop) continue;
+            if (down && best->face >= 0) {
+                float t_reach = (R[i].v[10] - r->oz) * inv_dz;  // parameter at which the ray reaches zmax
+                if (t_reach > best->t + (fabsf(best->t) * 1e-5f + 1e-6f)) { stop = 1; continue; }
+            }
+            mdp_rc_consider_rec(r, &R[i], best);
+        }
+    }
+}
+
 // ---- brute force (oracle + tiny meshes) ------------------------------------------------------
 MDP_RC_FN mdp_hit_t mdp_rc_brute(const mdp_mesh_view_t* m, const mdp_ray_t* r, float max_t) {
     mdp_hit_t best; best.t = max_t; best.face = -1;
@@ -180,7 +245,11 @@ MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, fl
     for (;;) {
         int32_t c = cy * m->ncx + cx;
         int32_t b = m->cell_start[c], e = m->cell_start[c + 1];
-        for (int32_t k = b; k < e; ++k) mdp_rc_consider(r, m->tri_verts, m->cell_tris[k], &best);
+        if (m->cell_recs) {
+            mdp_rc_cell_recs(m, r, b, e, &best);
+        } else {
+            for (int32_t k = b; k < e; ++k) mdp_rc_consider(r, m->tri_verts, m->cell_tris[k], &best);
+        }
         float tmx = sx != 0 ? ((m->gx0 + m->cell * (float)(cx + (sx > 0 ? 1 : 0))) - r->ox) / dx : BIG;
         float tmy = sy != 0 ? ((m->gy0 + m->cell * (float)(cy + (sy > 0 ? 1 : 0))) - r->oy) / dy : BIG;
         float t_exit = tmx < tmy ? tmx : tmy;
