@@ -50,6 +50,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=24)
     p.add_argument("--stats-every", type=int, default=24, help="rollout length between episode-stat all-reduces")
     p.add_argument("--small-terrain", action="store_true")
+    p.add_argument("--no-fuse-cast", action="store_true", help="cast the height scan in its own kernel")
     return p.parse_args()
 
 
@@ -106,6 +107,8 @@ def main():
     env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
                                  small_terrain=args.small_terrain, inject_random=False)
     env.observation_manager.persistent_output = True
+    if args.no_fuse_cast and "height_scanner" in env.scene.sensors:
+        env.scene.sensors["height_scanner"].fuse_into_observations = False
     # episode_length_buf ~ U{0..999}
     g = torch.Generator().manual_seed(99 + rank)
     env.episode_length_buf.copy_(torch.randint(0, 1000, (args.envs,), generator=g))

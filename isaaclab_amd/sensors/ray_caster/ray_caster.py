@@ -56,6 +56,7 @@ class RayCaster(SensorBase):
         # pose source in wxyz for the kernels: refreshed view of the physics transforms
         self._pose_wxyz = torch.zeros(num_envs, 13, device=device)
         self._pose_source = None
+        self.fuse_into_observations = True
 
     def bind_pose(self, root_state_fn):
         """Use an (N,13) wxyz root-state provider (ArticulationData.root_state_w) instead of converting the
@@ -64,7 +65,8 @@ class RayCaster(SensorBase):
 
     @property
     def can_fuse(self) -> bool:
-        return True
+        """Whether an ObservationManager may cast this sensor's rays inside its own kernel."""
+        return self.fuse_into_observations
 
     @property
     def data(self) -> RayCasterData:

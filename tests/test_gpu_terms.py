@@ -1,0 +1,252 @@
+"""GPU: stock MDP term library and the three fused managers (HIP through the C ABI) against the
+reference-generated fixtures (tests/golden/terms.npz, managers.npz).  Each term is evaluated through the
+reference call contract ``func(env, **params)`` (manager_base.py:250-267); the managers run their fused
+kernels.  Masks bit-exact, fp32 1e-5 relative (1e-5 absolute floor on sums of up to 51 squared terms)."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, to_np
+from duck import dev, make_device_env
+
+pytestmark = pytest.mark.gpu
+
+FEET, THIGHS, SOME_J = [13, 14, 15, 16], [5, 6, 7, 8], [0, 3, 7, 11]
+SUM_TOL = dict(rtol=1e-5, atol=1e-5)
+
+
+def cfg(name, joint_ids=None, body_ids=None):
+    from isaaclab_amd.managers import SceneEntityCfg
+
+    c = SceneEntityCfg(name)
+    if joint_ids is not None:
+        c.joint_ids = joint_ids
+    if body_ids is not None:
+        c.body_ids = body_ids
+    c.resolve = lambda scene: None   # ids are given explicitly (the fixtures were generated the same way)
+    return c
+
+
+@pytest.mark.parametrize("n", (1, 7, 64))
+def test_observation_terms(golden, device, n):
+    import isaaclab_amd.envs.mdp as mdp
+
+    G = golden("terms")
+    p = f"n{n}_"
+    env, _ = make_device_env(G, p, device)
+    O = {
+        "base_pos_z": mdp.base_pos_z(env), "base_lin_vel": mdp.base_lin_vel(env), "base_ang_vel": mdp.base_ang_vel(env),
+        "projected_gravity": mdp.projected_gravity(env), "root_pos_w": mdp.root_pos_w(env),
+        "root_quat_w": mdp.root_quat_w(env), "root_quat_w_unique": mdp.root_quat_w(env, make_quat_unique=True),
+        "root_lin_vel_w": mdp.root_lin_vel_w(env), "root_ang_vel_w": mdp.root_ang_vel_w(env),
+        "joint_pos": mdp.joint_pos(env), "joint_pos_sel": mdp.joint_pos(env, cfg("robot", SOME_J)),
+        "joint_pos_rel": mdp.joint_pos_rel(env), "joint_pos_rel_sel": mdp.joint_pos_rel(env, cfg("robot", SOME_J)),
+        "joint_pos_limit_normalized": mdp.joint_pos_limit_normalized(env), "joint_vel": mdp.joint_vel(env),
+        "joint_vel_rel": mdp.joint_vel_rel(env), "height_scan": mdp.height_scan(env, cfg("height_scanner")),
+        "last_action": mdp.last_action(env), "generated_commands": mdp.generated_commands(env, "base_velocity"),
+    }
+    for k, v in O.items():
+        assert_close(to_np(v), G[p + "obs_" + k], msg="obs " + k)
+
+
+@pytest.mark.parametrize("n", (1, 7, 64))
+def test_reward_terms(golden, device, n):
+    from types import SimpleNamespace
+
+    import isaaclab_amd.envs.mdp as mdp
+    import isaaclab_amd.tasks.velocity.mdp as vmdp
+
+    G = golden("terms")
+    p = f"n{n}_"
+    env, _ = make_device_env(G, p, device)
+    itt = mdp.is_terminated_term(SimpleNamespace(params={"term_keys": ".*"}), env)
+    R = {
+        "is_alive": mdp.is_alive(env), "is_terminated": mdp.is_terminated(env), "is_terminated_term": itt(env),
+        "lin_vel_z_l2": mdp.lin_vel_z_l2(env), "ang_vel_xy_l2": mdp.ang_vel_xy_l2(env),
+        "flat_orientation_l2": mdp.flat_orientation_l2(env), "base_height_l2": mdp.base_height_l2(env, 0.55),
+        "base_height_l2_sensor": mdp.base_height_l2(env, 0.55, sensor_cfg=cfg("height_scanner")),
+        "body_lin_acc_l2": mdp.body_lin_acc_l2(env, cfg("robot", body_ids=FEET)),
+        "joint_torques_l2": mdp.joint_torques_l2(env), "joint_vel_l1": mdp.joint_vel_l1(env, cfg("robot", SOME_J)),
+        "joint_vel_l2": mdp.joint_vel_l2(env), "joint_acc_l2": mdp.joint_acc_l2(env),
+        "joint_deviation_l1": mdp.joint_deviation_l1(env, cfg("robot", SOME_J)),
+        "joint_pos_limits": mdp.joint_pos_limits(env), "joint_vel_limits": mdp.joint_vel_limits(env, 0.9),
+        "applied_torque_limits": mdp.applied_torque_limits(env), "action_rate_l2": mdp.action_rate_l2(env),
+        "action_l2": mdp.action_l2(env),
+        "undesired_contacts": mdp.undesired_contacts(env, 1.0, cfg("contact_forces", body_ids=THIGHS)),
+        "contact_forces": mdp.contact_forces(env, 1.0, cfg("contact_forces", body_ids=FEET)),
+        "track_lin_vel_xy_exp": mdp.track_lin_vel_xy_exp(env, math.sqrt(0.25), "base_velocity"),
+        "track_ang_vel_z_exp": mdp.track_ang_vel_z_exp(env, math.sqrt(0.25), "base_velocity"),
+        "feet_air_time": vmdp.feet_air_time(env, "base_velocity", cfg("contact_forces", body_ids=FEET), 0.5),
+        "feet_air_time_positive_biped": vmdp.feet_air_time_positive_biped(
+            env, "base_velocity", 0.4, cfg("contact_forces", body_ids=FEET[:2])),
+        "feet_slide": vmdp.feet_slide(env, cfg("contact_forces", body_ids=FEET), cfg("robot", body_ids=FEET)),
+        "track_lin_vel_xy_yaw_frame_exp": vmdp.track_lin_vel_xy_yaw_frame_exp(env, 0.5, "base_velocity"),
+        "track_ang_vel_z_world_exp": vmdp.track_ang_vel_z_world_exp(env, "base_velocity", 0.5),
+    }
+    for k, v in R.items():
+        assert v.shape == (n,), k
+        assert_close(to_np(v.float()), G[p + "rew_" + k], msg="rew " + k, **SUM_TOL)
+
+
+@pytest.mark.parametrize("n", (1, 7, 64))
+def test_termination_terms(golden, device, n):
+    import torch
+
+    import isaaclab_amd.envs.mdp as mdp
+
+    G = golden("terms")
+    p = f"n{n}_"
+    env, _ = make_device_env(G, p, device)
+    T = {
+        "time_out": mdp.time_out(env), "command_resample": mdp.command_resample(env, "base_velocity", 1),
+        "bad_orientation": mdp.bad_orientation(env, 1.0),
+        "root_height_below_minimum": mdp.root_height_below_minimum(env, 0.55),
+        "joint_pos_out_of_manual_limit": mdp.joint_pos_out_of_manual_limit(env, (-0.9, 0.9), cfg("robot", SOME_J)),
+        "joint_vel_out_of_limit": mdp.joint_vel_out_of_limit(env),
+        "joint_vel_out_of_manual_limit": mdp.joint_vel_out_of_manual_limit(env, 6.0),
+        "joint_effort_out_of_limit": mdp.joint_effort_out_of_limit(env, cfg("robot", SOME_J)),
+        "illegal_contact": mdp.illegal_contact(env, 1.0, cfg("contact_forces", body_ids=[0])),
+    }
+    for k, v in T.items():
+        assert v.dtype == torch.bool and v.shape == (n,), k
+        np.testing.assert_array_equal(to_np(v), G[p + "term_" + k], err_msg="term " + k)   # bit-exact masks
+    # terminations.py:75-87 raises on use in the reference (indexing bug); reproduced, not fixed
+    assert int(G[p + "term_joint_pos_out_of_limit_raises"]) == 1
+    with pytest.raises(IndexError):
+        mdp.joint_pos_out_of_limit(env)
+
+
+@pytest.mark.parametrize("n", (7, 64))
+def test_managers(golden, device, n):
+    import isaaclab_amd.envs.mdp as mdp
+    import isaaclab_amd.managers as mg
+    import isaaclab_amd.tasks.velocity.mdp as vmdp
+    from isaaclab_amd.utils.noise import ConstantNoiseCfg
+
+    G = golden("managers")
+    p = f"n{n}_"
+    env, t = make_device_env(G, p, device)
+    rcfg = {
+        "track_lin_vel_xy_exp": mg.RewardTermCfg(func=mdp.track_lin_vel_xy_exp, weight=1.0,
+                                                 params={"command_name": "base_velocity", "std": math.sqrt(0.25)}),
+        "track_ang_vel_z_exp": mg.RewardTermCfg(func=mdp.track_ang_vel_z_exp, weight=0.5,
+                                                params={"command_name": "base_velocity", "std": math.sqrt(0.25)}),
+        "lin_vel_z_l2": mg.RewardTermCfg(func=mdp.lin_vel_z_l2, weight=-2.0),
+        "ang_vel_xy_l2": mg.RewardTermCfg(func=mdp.ang_vel_xy_l2, weight=-0.05),
+        "dof_torques_l2": mg.RewardTermCfg(func=mdp.joint_torques_l2, weight=-1.0e-5),
+        "dof_acc_l2": mg.RewardTermCfg(func=mdp.joint_acc_l2, weight=-2.5e-7),
+        "action_rate_l2": mg.RewardTermCfg(func=mdp.action_rate_l2, weight=-0.01),
+        "feet_air_time": mg.RewardTermCfg(func=vmdp.feet_air_time, weight=0.125,
+                                          params={"sensor_cfg": cfg("contact_forces", body_ids=FEET),
+                                                  "command_name": "base_velocity", "threshold": 0.5}),
+        "undesired_contacts": mg.RewardTermCfg(func=mdp.undesired_contacts, weight=-1.0,
+                                               params={"sensor_cfg": cfg("contact_forces", body_ids=THIGHS), "threshold": 1.0}),
+        "flat_orientation_l2": mg.RewardTermCfg(func=mdp.flat_orientation_l2, weight=0.0),
+        "dof_pos_limits": mg.RewardTermCfg(func=mdp.joint_pos_limits, weight=0.0),
+    }
+    rm = mg.RewardManager(rcfg, env)
+    r1 = to_np(rm.compute(0.02)).copy()
+    r2 = to_np(rm.compute(0.02)).copy()
+    assert_close(r1, G[p + "reward_1"], **SUM_TOL)
+    assert_close(r2, G[p + "reward_2"], **SUM_TOL)
+    sums = np.stack([to_np(rm._episode_sums[k]) for k in rm.active_terms])
+    assert_close(sums, G[p + "episode_sums"], **SUM_TOL)
+    assert_close(to_np(rm._step_reward), G[p + "step_reward"], rtol=1e-5, atol=1e-4)
+    # reset returns the episodic means and clears the sums (reward_manager.py:100-126)
+    extras = rm.reset([0, 2])
+    exp = float(G[p + "episode_sums"][0][[0, 2]].mean() / 20.0)
+    assert abs(float(extras["Episode_Reward/track_lin_vel_xy_exp"]) - exp) < 1e-5 * max(1.0, abs(exp))
+    assert float(rm._episode_sums["track_lin_vel_xy_exp"][0]) == 0.0
+
+    tcfg = {
+        "time_out": mg.TerminationTermCfg(func=mdp.time_out, time_out=True),
+        "base_contact": mg.TerminationTermCfg(func=mdp.illegal_contact,
+                                              params={"sensor_cfg": cfg("contact_forces", body_ids=[0]), "threshold": 1.0}),
+        "bad": mg.TerminationTermCfg(func=mdp.bad_orientation, params={"limit_angle": 1.0}),
+    }
+    tm = mg.TerminationManager(tcfg, env)
+    np.testing.assert_array_equal(to_np(tm.compute()), G[p + "dones"])
+    np.testing.assert_array_equal(to_np(tm.terminated), G[p + "terminated"])
+    np.testing.assert_array_equal(to_np(tm.time_outs), G[p + "time_outs"])
+    np.testing.assert_array_equal(np.stack([to_np(tm.get_term(k)) for k in tm.active_terms]), G[p + "term_dones"])
+
+    grp = mg.ObservationGroupCfg()
+    grp.enable_corruption = True
+    grp.concatenate_terms = True
+    grp.base_lin_vel = mg.ObservationTermCfg(func=mdp.base_lin_vel, noise=ConstantNoiseCfg(bias=0.05))
+    grp.base_ang_vel = mg.ObservationTermCfg(func=mdp.base_ang_vel, scale=0.25)
+    grp.projected_gravity = mg.ObservationTermCfg(func=mdp.projected_gravity, clip=(-0.5, 0.5))
+    grp.velocity_commands = mg.ObservationTermCfg(func=mdp.generated_commands, params={"command_name": "base_velocity"})
+    grp.joint_pos = mg.ObservationTermCfg(func=mdp.joint_pos_rel, noise=ConstantNoiseCfg(bias=1.1, operation="scale"))
+    grp.joint_vel = mg.ObservationTermCfg(func=mdp.joint_vel_rel, scale=tuple(0.05 * (i + 1) for i in range(12)))
+    grp.actions = mg.ObservationTermCfg(func=mdp.last_action)
+    grp.height_scan = mg.ObservationTermCfg(func=mdp.height_scan, params={"sensor_cfg": cfg("height_scanner")},
+                                            noise=ConstantNoiseCfg(bias=-0.02), clip=(-1.0, 1.0))
+    om = mg.ObservationManager({"policy": grp}, env)
+    assert om._group_fusable["policy"]
+    assert om.group_obs_dim["policy"] == (G[p + "obs"].shape[1],)
+    assert_close(to_np(om.compute()["policy"]), G[p + "obs"])
+
+    grp2 = mg.ObservationGroupCfg()
+    grp2.concatenate_terms = True
+    grp2.enable_corruption = False
+    grp2.history_length = 3
+    grp2.flatten_history_dim = True
+    grp2.base_lin_vel = mg.ObservationTermCfg(func=mdp.base_lin_vel)
+    grp2.joint_pos = mg.ObservationTermCfg(func=mdp.joint_pos_rel)
+    om2 = mg.ObservationManager({"policy": grp2}, env)
+    assert not om2._group_fusable["policy"]
+    assert_close(to_np(om2.compute()["policy"]), G[p + "obs_hist_1"])
+    t["joint_pos"] += 0.1
+    assert_close(to_np(om2.compute()["policy"]), G[p + "obs_hist_2"])
+    t["joint_pos"] -= 0.1
+
+
+def test_manager_errors_and_user_terms(golden, device):
+    """Error conventions of the reference (manager_base.py:236-298, observation_manager.py:425-437,
+    reward_manager.py:226-237) and user-defined (non-lowered) terms entering the fused kernels."""
+    import torch
+
+    import isaaclab_amd.envs.mdp as mdp
+    import isaaclab_amd.managers as mg
+
+    G = golden("terms")
+    env, t = make_device_env(G, "n7_", device)
+
+    def my_obs(env, gain: float = 2.0):
+        return env.scene["robot"].data.joint_vel[:, :3] * gain
+
+    def my_rew(env):
+        return env.scene["robot"].data.joint_pos[:, 0].abs()
+
+    grp = mg.ObservationGroupCfg()
+    grp.enable_corruption = False
+    grp.a = mg.ObservationTermCfg(func=mdp.base_lin_vel)
+    grp.b = mg.ObservationTermCfg(func=my_obs, params={"gain": 3.0}, clip=(-4.0, 4.0))
+    om = mg.ObservationManager({"policy": grp}, env)
+    out = to_np(om.compute()["policy"])
+    assert_close(out[:, :3], G["n7_obs_base_lin_vel"])
+    assert_close(out[:, 3:], np.clip(G["n7_in_joint_vel"][:, :3] * np.float32(3.0), -4, 4))
+    rm = mg.RewardManager({"x": mg.RewardTermCfg(func=my_rew, weight=2.0),
+                           "y": mg.RewardTermCfg(func=mdp.action_l2, weight=-1.0)}, env)
+    exp = (np.abs(G["n7_in_joint_pos"][:, 0]) * np.float32(2.0) * np.float32(0.1)
+           + G["n7_rew_action_l2"] * np.float32(-1.0) * np.float32(0.1))
+    assert_close(to_np(rm.compute(0.1)), exp, rtol=1e-5, atol=1e-6)
+    with pytest.raises(TypeError):
+        mg.RewardManager({"x": mg.RewardTermCfg(func=my_rew, weight="1")}, env)
+    def my_rew_k(env, k):
+        return env.scene["robot"].data.joint_pos[:, 0] * k
+
+    with pytest.raises(ValueError):     # parameter names must match the signature (manager_base.py:293-298)
+        mg.RewardManager({"x": mg.RewardTermCfg(func=my_rew_k, weight=1.0, params={"nope": 1})}, env)
+    with pytest.raises(TypeError):
+        mg.ObservationManager({"policy": {"a": 1}}, env)
+    bad = mg.ObservationGroupCfg()
+    bad.a = mg.ObservationTermCfg(func=mdp.joint_pos, scale=(1.0, 2.0))
+    with pytest.raises(ValueError):     # scale length mismatch
+        mg.ObservationManager({"policy": bad}, env)
+    with pytest.raises(ValueError):
+        om.compute_group("nope")
+    assert isinstance(str(om), str) and "policy" in str(om)
+    assert torch.is_tensor(rm._reward_buf)
