@@ -67,7 +67,11 @@ class ObsNormalizerStats:
         return self._partial
 
     def update(self, obs: torch.Tensor):
-        part = self.local_partial(obs)
+        self.merge_partial(self.local_partial(obs))
+
+    def merge_partial(self, part: torch.Tensor):
+        """Cross-rank step: all-gather the per-rank ``[n, sum x, M2]`` partials (RCCL on GPUs, gloo in the CPU tests),
+        Chan-merge them and fold the result into the running statistics."""
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             gathered = [torch.empty_like(part) for _ in range(dist.get_world_size(self.group))]
             dist.all_gather(gathered, part, group=self.group)
@@ -109,8 +113,7 @@ class EpisodeStats:
                 L.check(L.lib.mdp_stats_masked_sums(src.data_ptr(), rows, self.env.num_envs, L.ptr(mask),
                                                     self.payload[off:].data_ptr(), self._stream.cuda_stream))
                 off += 2 * rows
-            if self.world > 1:
-                self._work = dist.all_reduce(self.payload, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work = allreduce_payload(self.payload, self.world, self.group)
 
     def result(self) -> dict[str, float]:
         if self._work is not None:
@@ -119,6 +122,14 @@ class EpisodeStats:
         if self._stream is not None:
             self._stream.synchronize()
         return finalize_stats(self.names, self.payload.cpu(), self.env.max_episode_length_s)
+
+
+def allreduce_payload(payload: torch.Tensor, world: int, group=None):
+    """One asynchronous all-reduce(sum) of the packed ``[sum, count]`` vector; returns the work handle (None when
+    there is a single rank)."""
+    if world > 1:
+        return dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    return None
 
 
 def finalize_stats(names: list[str], payload: torch.Tensor, max_episode_length_s: float) -> dict[str, float]:

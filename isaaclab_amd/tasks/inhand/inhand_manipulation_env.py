@@ -1,0 +1,232 @@
+"""``InHandManipulationEnv`` (``TASKS/direct/inhand_manipulation/inhand_manipulation_env.py:29-433``) over a synthetic
+physics feed, stepped in the ``DirectRLEnv.step`` order (``LAB/envs/direct_rl_env.py:293-380``).
+
+The method names, buffers and return conventions are the reference's; the arithmetic of every method is one HIP
+kernel behind the C ABI (``mdp_inhand_*``).  ``consecutive_successes`` is the one cross-env reduction on the path
+(:424-431): its two partial sums are produced in fp64 per rank, optionally all-reduced (RCCL / gloo) and folded in
+by ``mdp_inhand_finish_rewards`` so the logged value is independent of how envs are sharded.
+Reset randomisation (``_reset_idx`` / ``_reset_target_pose``, :201-260) consumes the global torch generator in the
+reference and is kept on the host-visible torch path here (reset path is a "next" row).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from ... import _lib as L
+from ...assets import SyntheticPhysicsView
+from ...assets.articulation_data import ArticulationData
+from ...assets.rigid_object import RigidObject
+from .shadow_hand_env_cfg import ShadowHandEnvCfg
+
+
+class _ObjectView:
+    """Free-body physics view: ``get_transforms`` (N,7) xyzw + ``get_root_velocities`` (N,6)."""
+
+    def __init__(self, n: int, device: str):
+        self.count = n
+        self.transforms = torch.zeros(n, 7, device=device)
+        self.transforms[:, 6] = 1.0
+        self.velocities = torch.zeros(n, 6, device=device)
+
+    def get_transforms(self): return self.transforms
+    def get_root_velocities(self): return self.velocities
+
+
+class _Hand:
+    def __init__(self, cfg: ShadowHandEnvCfg, view: SyntheticPhysicsView, device: str):
+        self.joint_names = list(cfg.joint_names)
+        self.body_names = list(cfg.body_names)
+        self.num_joints = len(self.joint_names)
+        self.num_bodies = len(self.body_names)
+        self.root_physx_view = view
+        self.data = ArticulationData(view, device, body_names=self.body_names, joint_names=self.joint_names)
+        self.joint_pos_target = torch.zeros(view.count, self.num_joints, device=device)
+
+    def set_joint_position_target(self, target: torch.Tensor, joint_ids=None, env_ids=None):
+        """articulation.py:807-830"""
+        rows = slice(None) if env_ids is None else env_ids
+        cols = slice(None) if joint_ids is None else joint_ids
+        self.joint_pos_target[rows, cols] = target
+
+
+class InHandManipulationEnv:
+    cfg: ShadowHandEnvCfg
+
+    def __init__(self, cfg: ShadowHandEnvCfg, device: str = "cuda:0", env_origins: torch.Tensor | None = None,
+                 joint_pos_limits: torch.Tensor | None = None, group=None):
+        self.cfg = cfg
+        self.device = device
+        self.num_envs = n = cfg.num_envs
+        self.group = group              # torch.distributed process group for the sharded run (None = single rank)
+        self.extras: dict = {}
+        nj, nb = len(cfg.joint_names), len(cfg.body_names)
+        self.hand_view = SyntheticPhysicsView(n, nj, nb, device, num_contact_bodies=0)
+        self.object_view = _ObjectView(n, device)
+        self.hand = _Hand(cfg, self.hand_view, device)
+        self.object = RigidObject(self.object_view, device)
+        self.object.data.default_root_state[:, :3] = torch.tensor(cfg.object_init_pos, device=device)
+        self.scene = type("Scene", (), {})()
+        self.scene.env_origins = (torch.zeros(n, 3, device=device) if env_origins is None
+                                  else env_origins.to(device=device, dtype=torch.float32).contiguous())
+        # :32-77
+        self.num_hand_dofs = self.hand.num_joints
+        f = lambda *s: torch.zeros(s, dtype=torch.float32, device=device)
+        self.hand_dof_targets, self.prev_targets, self.cur_targets = f(n, nj), f(n, nj), f(n, nj)
+        self.actuated_dof_indices = sorted(self.hand.joint_names.index(j) for j in cfg.actuated_joint_names)
+        self.finger_bodies = sorted(self.hand.body_names.index(b) for b in cfg.fingertip_body_names)
+        self.num_fingertips = len(self.finger_bodies)
+        if joint_pos_limits is None:
+            joint_pos_limits = torch.tensor([-1.0, 1.0], device=device).repeat(n, nj, 1)
+        joint_pos_limits = joint_pos_limits.to(device=device, dtype=torch.float32)
+        self.hand_dof_lower_limits = joint_pos_limits[..., 0].contiguous()
+        self.hand_dof_upper_limits = joint_pos_limits[..., 1].contiguous()
+        self.reset_goal_buf = torch.zeros(n, dtype=torch.bool, device=device)
+        self.in_hand_pos = self.object.data.default_root_state[:, 0:3].clone()
+        self.in_hand_pos[:, 2] -= 0.04
+        self.goal_rot = f(n, 4)
+        self.goal_rot[:, 0] = 1.0
+        self.goal_pos = torch.tensor([-0.2, -0.45, 0.68], device=device).repeat(n, 1)
+        self.successes = f(n)
+        self.consecutive_successes = f(1)
+        self.x_unit_tensor = torch.tensor([1.0, 0, 0], device=device).repeat(n, 1)
+        self.y_unit_tensor = torch.tensor([0, 1.0, 0], device=device).repeat(n, 1)
+        self.z_unit_tensor = torch.tensor([0, 0, 1.0], device=device).repeat(n, 1)
+        # DirectRLEnv buffers (direct_rl_env.py:142-150)
+        self.actions = f(n, cfg.action_space)
+        self.episode_length_buf = torch.zeros(n, dtype=torch.long, device=device)
+        self.reset_terminated = torch.zeros(n, dtype=torch.bool, device=device)
+        self.reset_time_outs = torch.zeros(n, dtype=torch.bool, device=device)
+        self.reset_buf = torch.zeros(n, dtype=torch.bool, device=device)
+        self.reward_buf = f(n)
+        self.common_step_counter = 0
+        self._sim_step_counter = 0
+        # kernel-side constants
+        self._act_idx = torch.tensor(self.actuated_dof_indices, dtype=torch.int32, device=device)
+        self._fingers = torch.tensor(self.finger_bodies, dtype=torch.int32, device=device)
+        self._partials = torch.zeros(2, dtype=torch.float64, device=device)
+        self._obs = f(n, self.num_full_obs)
+        self._goal_resets = torch.zeros(n, dtype=torch.bool, device=device)
+        self._ccfg = self._make_cfg()
+
+    # -- properties (direct_rl_env.py:228-248) ----------------------------------------------------------
+    @property
+    def physics_dt(self) -> float: return self.cfg.sim_dt
+    @property
+    def step_dt(self) -> float: return self.cfg.sim_dt * self.cfg.decimation
+    @property
+    def max_episode_length_s(self) -> float: return self.cfg.episode_length_s
+    @property
+    def max_episode_length(self) -> int: return math.ceil(self.max_episode_length_s / self.step_dt)
+    @property
+    def num_full_obs(self) -> int:
+        return 2 * self.num_hand_dofs + 13 + 11 + 13 * self.num_fingertips + self.cfg.action_space
+
+    def _make_cfg(self) -> L.MdpInhandCfg:
+        c, k = L.MdpInhandCfg(), self.cfg
+        c.num_envs, c.num_dofs, c.num_actuated = self.num_envs, self.num_hand_dofs, len(self.actuated_dof_indices)
+        c.num_fingertips, c.num_bodies = self.num_fingertips, self.hand.num_bodies
+        c.act_moving_average, c.vel_obs_scale = k.act_moving_average, k.vel_obs_scale
+        c.dist_reward_scale, c.rot_reward_scale, c.rot_eps = k.dist_reward_scale, k.rot_reward_scale, k.rot_eps
+        c.action_penalty_scale, c.success_tolerance = k.action_penalty_scale, k.success_tolerance
+        c.reach_goal_bonus, c.fall_dist, c.fall_penalty, c.av_factor = k.reach_goal_bonus, k.fall_dist, k.fall_penalty, k.av_factor
+        c.max_consecutive_success, c.max_episode_length = k.max_consecutive_success, self.max_episode_length
+        return c
+
+    def refresh_cfg(self):
+        """Call after editing ``self.cfg`` scalars (the kernels take the constants by value)."""
+        self._ccfg = self._make_cfg()
+
+    # -- DirectRLEnv hooks --------------------------------------------------------------------------------
+    def _pre_physics_step(self, actions: torch.Tensor) -> None:
+        """:94-95"""
+        self.actions.copy_(actions)
+
+    def _apply_action(self) -> None:
+        """:97-117: scale -> moving average -> saturate on the actuated joints, targets handed to the articulation."""
+        L.check(L.lib.mdp_inhand_apply_action(C.byref(self._ccfg), L.ptr(self.actions), L.ptr(self._act_idx),
+                                              L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
+                                              L.ptr(self.cur_targets), L.ptr(self.prev_targets), L.stream()))
+        self.hand.set_joint_position_target(self.cur_targets[:, self.actuated_dof_indices],
+                                            joint_ids=self.actuated_dof_indices)
+
+    def _get_dones(self) -> tuple[torch.Tensor, torch.Tensor]:
+        """:179-199 (``_compute_intermediate_values`` is folded into the kernels: they read the raw state)."""
+        out_of_reach = torch.empty(self.num_envs, dtype=torch.bool, device=self.device)
+        time_out = torch.empty(self.num_envs, dtype=torch.bool, device=self.device)
+        L.check(L.lib.mdp_inhand_dones(C.byref(self._ccfg), L.ptr(self.object.data.root_state_w),
+                                       L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
+                                       L.ptr(self.successes), L.ptr(self.episode_length_buf), L.ptr(out_of_reach),
+                                       L.ptr(time_out), L.stream()))
+        return out_of_reach, time_out
+
+    def _get_rewards(self) -> torch.Tensor:
+        """:140-177 / compute_rewards :377-433"""
+        L.check(L.lib.mdp_inhand_rewards(C.byref(self._ccfg), L.ptr(self.object.data.root_state_w),
+                                         L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
+                                         L.ptr(self.actions), L.ptr(self.reset_buf), L.ptr(self.reset_goal_buf),
+                                         L.ptr(self.successes), L.ptr(self.reward_buf), L.ptr(self._goal_resets),
+                                         L.ptr(self._partials), L.stream()))
+        if self.group is not None:
+            import torch.distributed as dist
+
+            dist.all_reduce(self._partials, group=self.group)   # [sum resets, sum successes*resets], exact in fp64
+        L.check(L.lib.mdp_inhand_finish_rewards(C.byref(self._ccfg), L.ptr(self._partials),
+                                                L.ptr(self.consecutive_successes), L.stream()))
+        self.reset_goal_buf.copy_(self._goal_resets)
+        if "log" not in self.extras:
+            self.extras["log"] = dict()
+        self.extras["log"]["consecutive_successes"] = self.consecutive_successes.mean()
+        return self.reward_buf
+
+    def compute_full_observations(self) -> torch.Tensor:
+        """:298-322"""
+        L.check(L.lib.mdp_inhand_full_obs(C.byref(self._ccfg), L.ptr(self.hand.data.joint_pos),
+                                          L.ptr(self.hand.data.joint_vel), L.ptr(self.hand_dof_lower_limits),
+                                          L.ptr(self.hand_dof_upper_limits), L.ptr(self.object.data.root_state_w),
+                                          L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
+                                          L.ptr(self.hand.data.body_state_w), L.ptr(self._fingers), L.ptr(self.actions),
+                                          self.cfg.action_space, L.ptr(self._obs), self._obs.stride(0), L.stream()))
+        return self._obs
+
+    def _get_observations(self) -> dict:
+        """:119-138 (``obs_type == "full"``, symmetric)"""
+        if self.cfg.obs_type != "full" or self.cfg.asymmetric_obs:
+            raise NotImplementedError("only obs_type='full' without asymmetric observations is lowered to HIP")
+        return {"policy": self.compute_full_observations()}
+
+    def _reset_target_pose(self, env_ids):
+        """:248-260 (host torch path: consumes the global generator like the reference)."""
+        from ...utils.math import quat_from_angle_axis, quat_mul
+
+        k = len(env_ids)
+        rand = torch.rand((k, 2), device=self.device) * 2.0 - 1.0
+        new_rot = quat_mul(quat_from_angle_axis(rand[:, 0] * math.pi, self.x_unit_tensor[env_ids]),
+                           quat_from_angle_axis(rand[:, 1] * math.pi, self.y_unit_tensor[env_ids]))
+        self.goal_rot[env_ids] = new_rot
+        self.reset_goal_buf[env_ids] = False
+
+    # -- stepping (direct_rl_env.py:293-380) ------------------------------------------------------------
+    def step(self, action: torch.Tensor, reset_goals: bool = False):
+        self._pre_physics_step(action.to(self.device))
+        for _ in range(self.cfg.decimation):
+            self._sim_step_counter += 1
+            self._apply_action()
+            self.hand_view.advance()                      # sim.step(): synthetic / replayed
+            self.hand.data.update(self.physics_dt)
+            self.object.update(self.physics_dt)
+        self.episode_length_buf += 1
+        self.common_step_counter += 1
+        terminated, time_outs = self._get_dones()
+        self.reset_terminated[:] = terminated
+        self.reset_time_outs[:] = time_outs
+        torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
+        self.reward_buf = self._get_rewards()
+        if reset_goals:                                    # :172-175 (host sync, like the reference)
+            goal_env_ids = self.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)
+            if len(goal_env_ids) > 0:
+                self._reset_target_pose(goal_env_ids)
+        self.obs_buf = self._get_observations()
+        return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
