@@ -99,6 +99,51 @@ def test_oracle_grid_equals_brute():
     np.testing.assert_array_equal(a[0], b[0])
 
 
+def _moller_trumbore_f64(v, f, s, d):
+    """Independent float64 closest-hit brute force (Moller-Trumbore, two-sided): a second opinion on the restated
+    watertight test -- a different formula evaluated in a different precision by different code."""
+    tri = v[f].astype(np.float64)
+    a, e1, e2 = tri[:, 0], tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    best_t = np.full(len(s), np.inf)
+    best_f = np.full(len(s), -1, np.int64)
+    for i in range(len(s)):
+        o, dd = s[i].astype(np.float64), d[i].astype(np.float64)
+        p = np.cross(dd, e2)
+        det = (e1 * p).sum(1)
+        ok = np.abs(det) > 1e-14
+        inv = np.where(ok, 1.0 / np.where(ok, det, 1.0), 0.0)
+        tv = o - a
+        u = (tv * p).sum(1) * inv
+        q = np.cross(tv, e1)
+        w = (q * dd).sum(1) * inv
+        t = (q * e2).sum(1) * inv
+        eps = 1e-9
+        hit = ok & (u >= -eps) & (w >= -eps) & (u + w <= 1 + eps) & (t >= 0)
+        if hit.any():
+            t = np.where(hit, t, np.inf)
+            k = int(np.argmin(t))
+            best_t[i], best_f[i] = t[k], k
+    return best_t, best_f
+
+
+def test_oracle_vs_independent_float64_brute_force():
+    v, f = heightfield(3, n=24)
+    soup = RC.tri_soup(v, f)
+    for tilt in (0.0, 0.08):
+        s, d = rays_down(5, 800, 3.2, tilt=tilt)
+        hits, dist, _, face = RC.raycast_brute(soup, s, d)
+        t64, f64 = _moller_trumbore_f64(v, f, s, d)
+        assert np.array_equal(face >= 0, f64 >= 0)
+        h = face >= 0
+        assert h.sum() > 300
+        np.testing.assert_allclose(dist[h], t64[h], rtol=1e-5, atol=1e-5)
+        # the same triangle wins except where two candidates are closer than fp32 resolution (shared edges)
+        same = face[h] == f64[h]
+        assert same.mean() > 0.99
+        exp = s[h].astype(np.float64) + t64[h, None] * d[h].astype(np.float64)
+        np.testing.assert_allclose(hits[h], exp, rtol=1e-5, atol=2e-5)
+
+
 # ---- GPU ------------------------------------------------------------------------------------------------
 def _check_all_accels(device, v, f, s, d, max_dist=1e6):
     from isaaclab_amd.utils.warp import convert_to_warp_mesh, raycast_mesh
