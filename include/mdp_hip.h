@@ -180,6 +180,48 @@ int mdp_contact_sensor_reset(int num_envs, int num_bodies, int history_len,
 int mdp_sensor_tick(int num_envs, float* timestamp, const float* timestamp_last_update, uint8_t* is_outdated,
                     float dt, float update_period, void* stream);
 
+/* InteractiveScene.update (LAB/scene/interactive_scene.py:496-513) as ONE launch: everything the scene does
+ * between a physics step and the next reader -- ArticulationData.update (articulation_data.py:77-82: root_state_w
+ * assembly :264-279, joint state refresh :428-444, joint_acc finite difference :446-455), ContactSensor.update
+ * (sensor_base.py:197-205 + contact_sensor.py:314-373) and the timestamp / outdated bookkeeping of lazily evaluated
+ * sensors such as the RayCaster (sensor_base.py:197-205).  Every group is optional (NULL pointers skip it); the
+ * arithmetic of each group is exactly that of mdp_state_pack / mdp_joint_acc_update / mdp_contact_sensor_update /
+ * mdp_sensor_tick.  The *_src pointers are the physics view's buffers of the CURRENT frame (borrowed for the call:
+ * a replayed ring of frames is read in place, no staging copy); joint_pos / joint_vel are the state container's own
+ * buffers that later kernels (actuators, manager programs) bind to. */
+typedef struct {
+    int32_t num_envs, num_joints, num_contact_bodies, history_len;
+    const float* root_transforms;  /* (N,7) pos + quat xyzw */
+    const float* root_velocities;  /* (N,6) */
+    float* root_state_w;           /* (N,13) pos, quat wxyz, lin vel, ang vel */
+    const float* joint_pos_src;    /* (N,J) row stride ld_joint_src */
+    const float* joint_vel_src;
+    int32_t ld_joint_src;
+    float acc_elapsed;             /* time since joint_acc was last evaluated */
+    float* joint_pos;              /* (N,J) dense; may be NULL when the container aliases the physics buffer */
+    float* joint_vel;
+    float* prev_joint_vel;
+    float* joint_acc;
+    const float* net_contact_forces; /* (N,B,3) */
+    float* net_forces_w;
+    float* net_forces_w_history;
+    float* last_air_time;
+    float* current_air_time;
+    float* last_contact_time;
+    float* current_contact_time;
+    float* contact_timestamp;
+    float* contact_timestamp_last_update;
+    uint8_t* contact_is_outdated;
+    float contact_update_period, force_threshold;
+    int32_t contact_eager;
+    int32_t num_ticks;             /* lazily evaluated sensors (<= 4): timestamps + outdated flags only */
+    float* tick_timestamp[4];
+    const float* tick_timestamp_last_update[4];
+    uint8_t* tick_is_outdated[4];
+    float tick_update_period[4];
+} mdp_scene_update_t;
+int mdp_scene_update(const mdp_scene_update_t* desc, float dt, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray casting (LAB/utils/warp/ops.py:24-145, kernels.py:13-75; LAB/sensors/ray_caster/ray_caster.py:220-260)
  * ------------------------------------------------------------------------------------------ */
@@ -298,6 +340,15 @@ int mdp_reward_compute(mdp_program_t* prog, float dt, float* reward_buf, float* 
  * truncated/terminated (N) uint8, dones (N) = truncated | terminated (optional). */
 int mdp_termination_compute(mdp_program_t* prog, uint8_t* term_dones, uint8_t* truncated,
                             uint8_t* terminated, uint8_t* dones, void* stream);
+
+/* The post-physics prologue of ManagerBasedRLEnv.step in ONE launch (manager_based_rl_env.py:199-206):
+ * episode_length_buf += 1 (optional, int64 (N)), then TerminationManager.compute, then RewardManager.compute -- a block
+ * owns 64 envs, so the reward terms that read the termination buffers (rewards.py:31-38) see this step's flags.
+ * Output arguments as in mdp_termination_compute / mdp_reward_compute. */
+int mdp_termination_reward_compute(mdp_program_t* termination_prog, mdp_program_t* reward_prog, float dt,
+                                   int64_t* episode_length_buf_inc,
+                                   uint8_t* term_dones, uint8_t* truncated, uint8_t* terminated, uint8_t* dones,
+                                   float* reward_buf, float* episode_sums, float* step_reward, void* stream);
 
 /* Stand-alone evaluation of ONE lowered term (the stock `func(env, **params)` term functions call
  * this when used outside a manager; LAB/managers/manager_base.py:250-267 contract).  `term` is a

@@ -92,6 +92,26 @@ class MdpInhandCfg(C.Structure):
     ]
 
 
+class MdpSceneUpdate(C.Structure):
+    """Mirror of ``mdp_scene_update_t``."""
+
+    _fields_ = [
+        ("num_envs", C.c_int32), ("num_joints", C.c_int32), ("num_contact_bodies", C.c_int32), ("history_len", C.c_int32),
+        ("root_transforms", C.c_void_p), ("root_velocities", C.c_void_p), ("root_state_w", C.c_void_p),
+        ("joint_pos_src", C.c_void_p), ("joint_vel_src", C.c_void_p), ("ld_joint_src", C.c_int32),
+        ("acc_elapsed", C.c_float),
+        ("joint_pos", C.c_void_p), ("joint_vel", C.c_void_p), ("prev_joint_vel", C.c_void_p), ("joint_acc", C.c_void_p),
+        ("net_contact_forces", C.c_void_p), ("net_forces_w", C.c_void_p), ("net_forces_w_history", C.c_void_p),
+        ("last_air_time", C.c_void_p), ("current_air_time", C.c_void_p), ("last_contact_time", C.c_void_p),
+        ("current_contact_time", C.c_void_p), ("contact_timestamp", C.c_void_p),
+        ("contact_timestamp_last_update", C.c_void_p), ("contact_is_outdated", C.c_void_p),
+        ("contact_update_period", C.c_float), ("force_threshold", C.c_float), ("contact_eager", C.c_int32),
+        ("num_ticks", C.c_int32),
+        ("tick_timestamp", C.c_void_p * 4), ("tick_timestamp_last_update", C.c_void_p * 4),
+        ("tick_is_outdated", C.c_void_p * 4), ("tick_update_period", C.c_float * 4),
+    ]
+
+
 def _parse_defines(path: str, prefix: str) -> dict[str, int]:
     out = {}
     with open(path) as f:

@@ -32,9 +32,11 @@ class ArticulationData:
         self._root_link_state_w = TimestampedBuffer(f(n, 13))
         self._body_state_w = TimestampedBuffer(f(n, b, 13))
         self._body_link_state_w = TimestampedBuffer(f(n, b, 13))
-        self._body_acc_w = TimestampedBuffer()
-        self._joint_pos = TimestampedBuffer()
-        self._joint_vel = TimestampedBuffer()
+        self._body_acc_w = TimestampedBuffer(f(n, b, 6))
+        # the container owns its joint buffers (stable addresses for the fused programs); they are refreshed from
+        # the physics view's current buffers, which may be a different ring frame every step
+        self._joint_pos = TimestampedBuffer(f(n, j))
+        self._joint_vel = TimestampedBuffer(f(n, j))
         self._joint_acc = TimestampedBuffer(f(n, j))
         self._joint_acc.timestamp = 0.0
         self._previous_joint_vel = f(n, j)
@@ -69,6 +71,28 @@ class ArticulationData:
         """articulation_data.py:77-82: advance the timestamp and trigger the joint_acc finite difference."""
         self._sim_timestamp += dt
         self.joint_acc
+
+    # -- fused scene update (InteractiveScene.update -> mdp_scene_update) --------------------------------------
+    def fill_scene_update(self, d: "L.MdpSceneUpdate", dt: float):
+        """Describes this container's share of the fused post-physics launch: root_state_w assembly, joint state
+        refresh and the joint_acc finite difference, all from the physics view's CURRENT buffers."""
+        v = self._root_physx_view
+        d.num_envs, d.num_joints = self._num_instances, self._num_joints
+        d.root_transforms = v.get_root_transforms().data_ptr()
+        d.root_velocities = v.get_root_velocities().data_ptr()
+        d.root_state_w = self._root_state_w.data.data_ptr()
+        if self._num_joints > 0:
+            q, qd = v.get_dof_positions(), v.get_dof_velocities()
+            d.joint_pos_src, d.joint_vel_src, d.ld_joint_src = q.data_ptr(), qd.data_ptr(), q.stride(0)
+            d.joint_pos, d.joint_vel = self._joint_pos.data.data_ptr(), self._joint_vel.data.data_ptr()
+            d.prev_joint_vel, d.joint_acc = self._previous_joint_vel.data_ptr(), self._joint_acc.data.data_ptr()
+            d.acc_elapsed = (self._sim_timestamp + dt) - self._joint_acc.timestamp
+
+    def commit_scene_update(self, dt: float):
+        """Host-side bookkeeping after the fused launch: the buffers it wrote are fresh at the new timestamp."""
+        self._sim_timestamp += dt
+        for buf in (self._root_state_w, self._joint_pos, self._joint_vel, self._joint_acc):
+            buf.timestamp = self._sim_timestamp
 
     # -- lazily refreshed buffers ---------------------------------------------------------------------
     def _pack(self, pose, vel, out):
@@ -112,21 +136,21 @@ class ArticulationData:
     @property
     def body_acc_w(self):
         if self._body_acc_w.timestamp < self._sim_timestamp:
-            self._body_acc_w.data = self._root_physx_view.get_link_accelerations()
+            self._body_acc_w.data.copy_(self._root_physx_view.get_link_accelerations())
             self._body_acc_w.timestamp = self._sim_timestamp
         return self._body_acc_w.data
 
     @property
     def joint_pos(self):
         if self._joint_pos.timestamp < self._sim_timestamp:
-            self._joint_pos.data = self._root_physx_view.get_dof_positions()
+            self._joint_pos.data.copy_(self._root_physx_view.get_dof_positions())
             self._joint_pos.timestamp = self._sim_timestamp
         return self._joint_pos.data
 
     @property
     def joint_vel(self):
         if self._joint_vel.timestamp < self._sim_timestamp:
-            self._joint_vel.data = self._root_physx_view.get_dof_velocities()
+            self._joint_vel.data.copy_(self._root_physx_view.get_dof_velocities())
             self._joint_vel.timestamp = self._sim_timestamp
         return self._joint_vel.data
 

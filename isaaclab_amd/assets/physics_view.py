@@ -5,8 +5,10 @@ PhysX / Isaac Sim are out of scope: this object exposes th
 (articulation_data.py:273-275,340-342,406,432,441; contact_sensor.py:323; ray_caster.py:226) and is
 fed either by direct writes or by replaying a ring of pre-generated state frames.
 
-All tensors are views into ONE flat device buffer (``live``), so "stepping physics" in replay mode is
-a single contiguous device copy of the next frame (``advance()``), capturable in a hipGraph.
+All tensors are views into ONE flat device buffer: ``live`` for direct writes, or -- in replay mode -- the current
+frame of a ring resident in HBM.  "Stepping physics" (``advance()``) then only moves the cursor: the getters hand out
+views of the next frame in place (zero copy), exactly as a physics engine hands out its own state buffers, and the
+pointers baked into a captured hipGraph are those of the ring.
 Quaternions follow the physics convention (x, y, z, w).
 """
 from __future__ import annotations
@@ -53,18 +55,30 @@ class SyntheticPhysicsView:
         self.coms[..., 6] = 1.0
         self._frames: torch.Tensor | None = None
         self._cursor = 0
+        self._current: int | None = None       # ring frame the getters expose (None = ``live``)
+        self._frame_views: dict[int, dict] = {}
 
     # -- getters with the PhysX view names -----------------------------------------------------------
-    def get_root_transforms(self): return self._views["root_transforms"]
-    def get_root_velocities(self): return self._views["root_velocities"]
-    def get_dof_positions(self): return self._views["dof_positions"]
-    def get_dof_velocities(self): return self._views["dof_velocities"]
-    def get_link_transforms(self): return self._views["link_transforms"]
-    def get_link_velocities(self): return self._views["link_velocities"]
-    def get_link_accelerations(self): return self._views["link_accelerations"]
+    def _field(self, name: str) -> torch.Tensor:
+        if self._current is None:
+            return self._views[name]
+        views = self._frame_views.get(self._current)
+        if views is None:
+            frame = self._frames[self._current]
+            views = {k: frame[o : o + s].view(self._shapes[k]) for k, (o, s) in self._slices.items()}
+            self._frame_views[self._current] = views
+        return views[name]
+
+    def get_root_transforms(self): return self._field("root_transforms")
+    def get_root_velocities(self): return self._field("root_velocities")
+    def get_dof_positions(self): return self._field("dof_positions")
+    def get_dof_velocities(self): return self._field("dof_velocities")
+    def get_link_transforms(self): return self._field("link_transforms")
+    def get_link_velocities(self): return self._field("link_velocities")
+    def get_link_accelerations(self): return self._field("link_accelerations")
     def get_coms(self): return self.coms
-    def get_net_contact_forces(self, dt: float | None = None): return self._views["net_contact_forces"]
-    def get_transforms(self): return self._views["root_transforms"]
+    def get_net_contact_forces(self, dt: float | None = None): return self._field("net_contact_forces")
+    def get_transforms(self): return self._field("root_transforms")
 
     # -- replay ---------------------------------------------------------------------------------------
     def field_view(self, frames: torch.Tensor, name: str) -> torch.Tensor:
@@ -77,14 +91,16 @@ class SyntheticPhysicsView:
             raise ValueError(f"frames must be (T, {self.frame_size}), got {tuple(frames.shape)}")
         self._frames = frames.to(self.device, dtype=torch.float32).contiguous()
         self._cursor = 0
+        self._current = None                   # ``live`` stays current until the first advance()
+        self._frame_views = {}
 
     @property
     def num_frames(self) -> int:
         return 0 if self._frames is None else self._frames.shape[0]
 
     def advance(self):
-        """'Physics step' in replay mode: live <- next frame of the ring."""
+        """'Physics step' in replay mode: the next frame of the ring becomes the one the getters expose."""
         if self._frames is None:
             return
-        self.live.copy_(self._frames[self._cursor], non_blocking=True)
+        self._current = self._cursor
         self._cursor = (self._cursor + 1) % self._frames.shape[0]

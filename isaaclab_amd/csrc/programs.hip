@@ -608,6 +608,64 @@ __global__ void k_termination(const mdp_term_t* __restrict__ terms, int T, const
     }
 }
 
+// manager_based_rl_env.py:199-206 in one launch: episode_length_buf += 1, terminations, rewards.  A block owns 64
+// consecutive envs; wave w evaluates term w, w + nwaves, ... for those envs (wave-uniform opcode, coalesced reads).
+// The termination flags are committed to global memory and a block barrier separates them from the reward phase, so
+// reward terms that read `terminated` / `term_dones` through their bound pointers see this step's values.
+__global__ void k_term_reward(const mdp_term_t* __restrict__ tterms, int Tt, const int32_t* __restrict__ tpool,
+                              const mdp_term_t* __restrict__ rterms, int Tr, const int32_t* __restrict__ rpool, int N,
+                              float dt, int64_t* len_inc, uint8_t* term_dones, uint8_t* truncated, uint8_t* terminated,
+                              uint8_t* dones, float* reward, float* sums, float* step) {
+    extern __shared__ float s_val[];  // [max(Tt, Tr)][64]
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int nwaves = blockDim.x >> 6;
+    for (int base = blockIdx.x * 64; base < N; base += gridDim.x * 64) {
+        int e = base + lane;
+        if (len_inc) {
+            if (wave == 0 && e < N) len_inc[e] += 1;
+            __syncthreads();
+        }
+        for (int ti = wave; ti < Tt; ti += nwaves) {
+            const mdp_term_t& t = tterms[ti];
+            bool v = e < N ? term_value(t, tpool, e) : false;
+            if (term_dones && e < N) term_dones[(int64_t)t.out_offset * N + e] = v ? 1 : 0;
+            s_val[ti * 64 + lane] = v ? 1.0f : 0.0f;
+        }
+        __syncthreads();
+        if (wave == 0 && e < N && Tt > 0) {
+            bool trunc = false, term = false;
+            for (int ti = 0; ti < Tt; ++ti) {
+                bool v = s_val[ti * 64 + lane] != 0.0f;
+                if (tterms[ti].i3) trunc = trunc || v; else term = term || v;
+            }
+            if (truncated) truncated[e] = trunc ? 1 : 0;
+            if (terminated) terminated[e] = term ? 1 : 0;
+            if (dones) dones[e] = (trunc || term) ? 1 : 0;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int ti = wave; ti < Tr; ti += nwaves) {
+            const mdp_term_t& t = rterms[ti];
+            float value = 0.0f;
+            if (e < N && t.weight != 0.0f) {
+                value = reward_value(t, rpool, e, N) * t.weight * dt;
+                if (sums) sums[(int64_t)t.out_offset * N + e] += value;
+                if (step) step[(int64_t)e * Tr + t.out_offset] = value / dt;
+            }
+            s_val[ti * 64 + lane] = value;
+        }
+        __syncthreads();
+        if (wave == 0 && e < N && Tr > 0) {
+            float total = 0.0f;
+            for (int ti = 0; ti < Tr; ++ti)
+                if (rterms[ti].weight != 0.0f) total += s_val[ti * 64 + lane];
+            reward[e] = total;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- single-term evaluation: the term travels as a kernel argument (no allocation, no sync) ----
 __global__ void k_obs_single(mdp_term_t t, const int32_t* __restrict__ pool, int N, float* __restrict__ out, int ld,
                              uint64_t seed, uint64_t epoch) {
@@ -781,6 +839,28 @@ extern "C" int mdp_termination_compute(mdp_program_t* p, uint8_t* term_dones, ui
     if (p->num_envs == 0) return MDP_OK;
     hipLaunchKernelGGL(k_termination, dim3(grid_for(p->num_envs, 64, 1 << 20)), dim3(64), 0, as_stream(stream),
                        p->d_terms, p->num_terms, p->d_pool, p->num_envs, term_dones, truncated, terminated, dones);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_termination_reward_compute(mdp_program_t* tp, mdp_program_t* rp, float dt,
+                                              int64_t* episode_length_buf_inc, uint8_t* term_dones,
+                                              uint8_t* truncated, uint8_t* terminated, uint8_t* dones,
+                                              float* reward_buf, float* episode_sums, float* step_reward,
+                                              void* stream) {
+    MDP_REQUIRE(tp && tp->kind == MDP_PROG_TERMINATION, "not a termination program");
+    MDP_REQUIRE(rp && rp->kind == MDP_PROG_REWARD, "not a reward program");
+    MDP_REQUIRE(tp->num_envs == rp->num_envs && tp->device == rp->device, "programs disagree on num_envs / device");
+    MDP_REQUIRE(reward_buf || rp->num_terms == 0, "null reward buffer");
+    if (tp->num_envs == 0) return MDP_OK;
+    int tmax = tp->num_terms > rp->num_terms ? tp->num_terms : rp->num_terms;
+    int waves = tmax < 1 ? 1 : (tmax > 16 ? 16 : tmax);
+    size_t lds = (size_t)(tmax > 0 ? tmax : 1) * 64 * sizeof(float);
+    if (lds > 60 * 1024) return fail(MDP_ERR_UNSUPPORTED, "%d terms exceed the LDS staging area", tmax);
+    hipLaunchKernelGGL(k_term_reward, dim3(grid_for(tp->num_envs, 64, 1 << 20)), dim3(64 * waves), lds,
+                       as_stream(stream), tp->d_terms, tp->num_terms, tp->d_pool, rp->d_terms, rp->num_terms, rp->d_pool,
+                       tp->num_envs, dt, episode_length_buf_inc, term_dones, truncated, terminated, dones, reward_buf,
+                       episode_sums, step_reward);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -30,6 +30,7 @@ class ManagerBasedRLEnv:
         self.device = device
         self.num_envs = cfg.scene.num_envs
         self.auto_reset = auto_reset
+        self.fuse_post_physics = True   # episode counter + terminations + rewards in one launch
         self.extras: dict[str, Any] = {}
         robot_cfg = cfg.scene.robot
         nj, nb = len(robot_cfg.joint_names), len(robot_cfg.body_names)
@@ -94,12 +95,15 @@ class ManagerBasedRLEnv:
             self.scene.write_data_to_sim()
             self.physics.advance()                      # sim.step(render=False): synthetic / replayed
             self.scene.update(dt=self.physics_dt)
-        self.episode_length_buf += 1
         self.common_step_counter += 1
-        self.reset_buf = self.termination_manager.compute()
+        if self.fuse_post_physics and self._can_fuse_post_physics():
+            self._termination_reward_fused()
+        else:
+            self.episode_length_buf += 1
+            self.reset_buf = self.termination_manager.compute()
+            self.reward_buf = self.reward_manager.compute(dt=self.step_dt)
         self.reset_terminated = self.termination_manager.terminated
         self.reset_time_outs = self.termination_manager.time_outs
-        self.reward_buf = self.reward_manager.compute(dt=self.step_dt)
         if self.auto_reset:
             reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
             if len(reset_env_ids) > 0:
@@ -107,6 +111,29 @@ class ManagerBasedRLEnv:
         self.command_manager.compute(dt=self.step_dt)
         self.obs_buf = self.observation_manager.compute()
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    def _can_fuse_post_physics(self) -> bool:
+        tm, rm = self.termination_manager, self.reward_manager
+        # user-defined (non-lowered) terms may read the episode counter or the termination buffers from Python
+        if tm._program is None or rm._program is None:
+            return False            # first step: the unfused calls build the programs (and discover user terms)
+        return (len(tm.active_terms) > 0 and len(rm.active_terms) > 0 and not tm._external and not rm._external)
+
+    def _termination_reward_fused(self):
+        """manager_based_rl_env.py:199-206: ``episode_length_buf += 1``, ``termination_manager.compute()`` and
+        ``reward_manager.compute(dt)`` as one kernel launch (``mdp_termination_reward_compute``)."""
+        from .. import _lib as L
+
+        tm, rm = self.termination_manager, self.reward_manager
+        tp = tm.prepare_launch()
+        rp = rm.prepare_launch()
+        L.check(L.lib.mdp_termination_reward_compute(
+            tp.handle, rp.handle, float(self.step_dt), self.episode_length_buf.data_ptr(),
+            tm._term_dones_block.data_ptr(), tm._truncated_buf.data_ptr(), tm._terminated_buf.data_ptr(),
+            tm._dones_buf.data_ptr(), rm._reward_buf.data_ptr(), rm._episode_sums_block.data_ptr(),
+            rm._step_reward.data_ptr(), L.stream(self.device)))
+        self.reset_buf = tm._dones_buf
+        self.reward_buf = rm._reward_buf
 
     def _reset_idx(self, env_ids):
         """manager_based_rl_env.py:346-391 without events / curriculum (out of scope)."""

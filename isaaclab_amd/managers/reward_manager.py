@@ -75,10 +75,9 @@ class RewardManager(ManagerBase):
         self._bound_funcs = tuple(id(c.func) for c in self._term_cfgs)
         return Program(REWARD, self.num_envs, self.device, specs, structs_post=post)
 
-    def compute(self, dt: float) -> torch.Tensor:
-        if len(self._term_names) == 0:
-            self._reward_buf[:] = 0.0
-            return self._reward_buf
+    def prepare_launch(self):
+        """Everything ``compute`` does before its kernel launch: (re)build the program when weights / functions
+        changed, evaluate user-defined (non-lowered) terms, refresh lazily evaluated inputs."""
         weights = tuple(float(c.weight) for c in self._term_cfgs)
         funcs = tuple(id(c.func) for c in self._term_cfgs)
         if self._program is None or weights != self._bound_weights or funcs != self._bound_funcs:
@@ -86,6 +85,13 @@ class RewardManager(ManagerBase):
         for term_cfg, staging in self._external:
             staging.copy_(term_cfg.func(self._env, **term_cfg.params))
         self._program.run_before()
+        return self._program
+
+    def compute(self, dt: float) -> torch.Tensor:
+        if len(self._term_names) == 0:
+            self._reward_buf[:] = 0.0
+            return self._reward_buf
+        self.prepare_launch()
         L.check(L.lib.mdp_reward_compute(self._program.handle, float(dt), self._reward_buf.data_ptr(),
                                          self._episode_sums_block.data_ptr(), self._step_reward.data_ptr(),
                                          L.stream(self.device)))

@@ -79,9 +79,8 @@ class TerminationManager(ManagerBase):
         self._bound = tuple((id(c.func), bool(c.time_out)) for c in self._term_cfgs)
         return Program(TERMINATION, self.num_envs, self.device, specs, structs_post=post)
 
-    def compute(self) -> torch.Tensor:
-        if len(self._term_names) == 0:
-            return self._dones_buf
+    def prepare_launch(self):
+        """Everything ``compute`` does before its kernel launch (program rebuild, user terms, lazy inputs)."""
         bound = tuple((id(c.func), bool(c.time_out)) for c in self._term_cfgs)
         if self._program is None or bound != self._bound:
             self._program = self._build_program()
@@ -92,6 +91,12 @@ class TerminationManager(ManagerBase):
             else:
                 staging.fill_(bool(value))
         self._program.run_before()
+        return self._program
+
+    def compute(self) -> torch.Tensor:
+        if len(self._term_names) == 0:
+            return self._dones_buf
+        self.prepare_launch()
         L.check(L.lib.mdp_termination_compute(self._program.handle, self._term_dones_block.data_ptr(),
                                               self._truncated_buf.data_ptr(), self._terminated_buf.data_ptr(),
                                               self._dones_buf.data_ptr(), L.stream(self.device)))

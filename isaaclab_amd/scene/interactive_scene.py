@@ -17,6 +17,7 @@ class InteractiveScene:
         self.env_origins = (env_origins if env_origins is not None
                             else torch.zeros((num_envs, 3), dtype=torch.float32, device=device))
         self.lazy_sensor_update = True
+        self.fused_update = True
 
     def keys(self) -> list[str]:
         keys = ["terrain"] if self.terrain is not None else []
@@ -45,10 +46,42 @@ class InteractiveScene:
             obj.write_data_to_sim()
 
     def update(self, dt: float) -> None:
-        """interactive_scene.py:496-513"""
+        """interactive_scene.py:496-513.  With one articulation and sensors that know how to describe their share
+        (``fill_scene_update`` / ``fill_scene_tick``) the whole fan-out is ONE kernel launch (``mdp_scene_update``);
+        anything else goes through the per-entity ``update`` calls below."""
+        if self.fused_update and self._update_fused(dt):
+            return
         for articulation in self.articulations.values():
             articulation.update(dt)
         for obj in self.rigid_objects.values():
             obj.update(dt)
         for sensor in self.sensors.values():
             sensor.update(dt, force_recompute=not self.lazy_sensor_update)
+
+    def _update_fused(self, dt: float) -> bool:
+        import ctypes as C
+
+        from .. import _lib as L
+
+        if len(self.articulations) != 1 or self.rigid_objects:
+            return False
+        art = next(iter(self.articulations.values()))
+        if not hasattr(art.data, "fill_scene_update"):
+            return False
+        d = L.MdpSceneUpdate()
+        force = not self.lazy_sensor_update
+        seen_contact = False
+        for sensor in self.sensors.values():
+            if hasattr(sensor, "fill_scene_update") and not seen_contact:
+                if not sensor.fill_scene_update(d, force):
+                    return False
+                seen_contact = True
+            elif hasattr(sensor, "fill_scene_tick"):
+                if not sensor.fill_scene_tick(d, force):
+                    return False
+            else:
+                return False
+        art.data.fill_scene_update(d, dt)
+        L.check(L.lib.mdp_scene_update(C.byref(d), float(dt), L.stream(self.device)))
+        art.data.commit_scene_update(dt)
+        return True

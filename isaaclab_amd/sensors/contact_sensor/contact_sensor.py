@@ -81,6 +81,26 @@ class ContactSensor(SensorBase):
                                                 float(self.cfg.update_period), float(self.cfg.force_threshold),
                                                 1 if eager else 0, L.stream()))
 
+    def fill_scene_update(self, d: "L.MdpSceneUpdate", force_recompute: bool = False) -> bool:
+        """This sensor's share of the fused post-physics launch (``InteractiveScene.update``)."""
+        if self._num_bodies > 256 or self._num_bodies == 0:
+            return False
+        dd = self._data
+        d.num_contact_bodies, d.history_len = self._num_bodies, self.cfg.history_length
+        d.net_contact_forces = self._contact_physx_view.get_net_contact_forces(dt=self._sim_physics_dt).data_ptr()
+        d.net_forces_w = dd.net_forces_w.data_ptr()
+        d.net_forces_w_history = dd.net_forces_w_history.data_ptr() if self.cfg.history_length > 0 else None
+        if self.cfg.track_air_time:
+            d.last_air_time, d.current_air_time = dd.last_air_time.data_ptr(), dd.current_air_time.data_ptr()
+            d.last_contact_time = dd.last_contact_time.data_ptr()
+            d.current_contact_time = dd.current_contact_time.data_ptr()
+        d.contact_timestamp = self._timestamp.data_ptr()
+        d.contact_timestamp_last_update = self._timestamp_last_update.data_ptr()
+        d.contact_is_outdated = self._is_outdated.data_ptr()
+        d.contact_update_period, d.force_threshold = float(self.cfg.update_period), float(self.cfg.force_threshold)
+        d.contact_eager = 1 if (force_recompute or self._is_visualizing or self.cfg.history_length > 0) else 0
+        return True
+
     def update(self, dt: float, force_recompute: bool = False):
         """sensor_base.py:197-205 (timestamps, outdated flags) fused with the buffer update."""
         eager = force_recompute or self._is_visualizing or (self.cfg.history_length > 0)

@@ -81,6 +81,19 @@ class RayCaster(SensorBase):
         if lo != 0.0 or hi != 0.0:
             self.drift[env_ids] = self.drift[env_ids].uniform_(lo, hi)
 
+    def fill_scene_tick(self, d: "L.MdpSceneUpdate", force_recompute: bool = False) -> bool:
+        """Registers the timestamp / outdated bookkeeping of this lazily evaluated sensor with the fused
+        post-physics launch (sensor_base.py:197-205); the cast itself stays lazy."""
+        if force_recompute or self._is_visualizing or self.cfg.history_length > 0 or d.num_ticks >= 4:
+            return False
+        k = d.num_ticks
+        d.tick_timestamp[k] = self._timestamp.data_ptr()
+        d.tick_timestamp_last_update[k] = self._timestamp_last_update.data_ptr()
+        d.tick_is_outdated[k] = self._is_outdated.data_ptr()
+        d.tick_update_period[k] = float(self.cfg.update_period)
+        d.num_ticks = k + 1
+        return True
+
     def update(self, dt: float, force_recompute: bool = False):
         L.check(L.lib.mdp_sensor_tick(self._num_envs, L.ptr(self._timestamp), L.ptr(self._timestamp_last_update),
                                       L.ptr(self._is_outdated), float(dt), float(self.cfg.update_period), L.stream()))
