@@ -248,11 +248,14 @@ int mdp_raycast(const mdp_mesh_t* mesh, int64_t num_rays,
  * (ray_caster.py:220-260, sensor_base.py:284-293): for every env whose is_outdated flag is set
  * (or all when is_outdated == NULL): pos_w = root_pos + drift, quat_w = root quat, rays from the
  * (R,3) local pattern (yaw-only or full attach), cast, write ray_hits_w (N,R,3); then
- * last_update = timestamp, outdated = 0.  root_pose: (N, >=7) [pos, quat wxyz] with row stride ld. */
+ * last_update = timestamp, outdated = 0.  root_pose: (N, >=7) [pos, quat wxyz] with row stride ld.
+ * pattern_vertical_down != 0 is the caller's promise that every local direction is (0, 0, -c), c > 0 (the height-scan
+ * grid pattern, patterns.py:42-56): with yaw-only attachment the rays are then vertical in the world and a
+ * specialised kernel (same arithmetic, half the registers, one grid cell per ray) is used. */
 int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int num_rays,
                          const float* root_pose, int ld_pose, const float* drift,
                          const float* ray_starts_local, const float* ray_dirs_local,
-                         int attach_yaw_only, float max_dist,
+                         int attach_yaw_only, int pattern_vertical_down, float max_dist,
                          float* pos_w, float* quat_w, float* ray_hits_w,
                          const float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
                          void* stream);

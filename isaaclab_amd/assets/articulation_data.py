@@ -70,6 +70,9 @@ class ArticulationData:
     def update(self, dt: float):
         """articulation_data.py:77-82: advance the timestamp and trigger the joint_acc finite difference."""
         self._sim_timestamp += dt
+        # the joint buffers are this container's own copies (stable addresses bound by the fused programs): refresh
+        # them eagerly, the reference's ``joint_pos`` is a live view of the physics buffer
+        self.joint_pos
         self.joint_acc
 
     # -- fused scene update (InteractiveScene.update -> mdp_scene_update) --------------------------------------

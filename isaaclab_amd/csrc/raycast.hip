@@ -182,6 +182,15 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
             std::nth_element(sizes.begin(), sizes.begin() + sizes.size() / 2, sizes.end());
             cell = sizes[sizes.size() / 2];
         }
+        // half the lattice pitch: ~5 records per cell instead of ~6.4 and, more importantly, most vertical rays
+        // finish within their first two records (measured on the 1.16 M-triangle terrain: 41 -> 33 us per
+        // 766 k-ray height scan).  MDP_GRID_CELL_SCALE overrides the factor (tools/bench_stages.py).
+        double f = 0.5;
+        if (const char* sc = std::getenv("MDP_GRID_CELL_SCALE")) {
+            double g = std::atof(sc);
+            if (g > 0.0) f = g;
+        }
+        cell *= f;
         cell = std::max(cell, 1e-4);
     }
     // memory guards: at most 8 M cells and (bounding-box estimate) 48 M cell references (48 B each)
@@ -363,18 +372,26 @@ extern "C" int mdp_mesh_info(const mdp_mesh_t* mesh, int64_t* num_tris, int64_t*
 // =============================================================================================
 namespace {
 
+// compile-time traversal choice: the grid instantiation carries neither the BVH stack (scratch) nor its code
+template <int ACCEL>
+__device__ __forceinline__ mdp_hit_t rc_query(const mdp_mesh_view_t* m, const mdp_ray_t* r, float max_t) {
+    if (ACCEL == 2) return mdp_rc_bvh(m, r, max_t);
+    if (ACCEL == 1) return mdp_rc_grid(m, r, max_t);
+    return mdp_rc_brute(m, r, max_t);
+}
+
 // ops.py:61-127 + kernels.py:55-75: one thread per ray
+template <int ACCEL>
 __global__ void k_raycast(mdp_mesh_view_t mesh, int64_t num_rays, const float* __restrict__ starts,
                           const float* __restrict__ dirs, float max_dist, float* __restrict__ hits,
-                          float* __restrict__ dist, float* __restrict__ normal, int32_t* __restrict__ face,
-                          int accel) {
+                          float* __restrict__ dist, float* __restrict__ normal, int32_t* __restrict__ face) {
     const float inf = __builtin_inff();
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < num_rays;
          i += (int64_t)gridDim.x * blockDim.x) {
         float ox = starts[3 * i], oy = starts[3 * i + 1], oz = starts[3 * i + 2];
         float dx = dirs[3 * i], dy = dirs[3 * i + 1], dz = dirs[3 * i + 2];
         mdp_ray_t r = mdp_rc_make_ray(ox, oy, oz, dx, dy, dz);
-        mdp_hit_t h = mdp_rc_query(&mesh, &r, max_dist, accel);
+        mdp_hit_t h = rc_query<ACCEL>(&mesh, &r, max_dist);
         if (h.face >= 0) {
             // kernels.py:69: ray_hits = start + t * dir
             hits[3 * i] = ox + h.t * dx;
@@ -399,6 +416,7 @@ __global__ void k_raycast(mdp_mesh_view_t mesh, int64_t num_rays, const float* _
 // ray_caster.py:220-260 with the lazy-update bookkeeping of sensor_base.py:284-293.
 // A block owns whole environments (slot_w threads each) so the outdated flag can be read by every
 // ray thread and cleared by the env's first thread after a block barrier.
+template <int ACCEL>
 __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w,
                                    const float* __restrict__ pose, int ld_pose, const float* __restrict__ drift,
                                    const float* __restrict__ starts_l, const float* __restrict__ dirs_l,
@@ -426,7 +444,54 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
                 V3 d = ld3(dirs_l + 3 * r);
                 if (!yaw_only) d = quat_apply(q, d);
                 mdp_ray_t ray = mdp_rc_make_ray(s.x, s.y, s.z, d.x, d.y, d.z);
-                mdp_hit_t h = mdp_rc_query(&mesh, &ray, max_dist, mesh.accel);
+                mdp_hit_t h = rc_query<ACCEL>(&mesh, &ray, max_dist);
+                float* o = hits + ((int64_t)e * R + r) * 3;
+                if (h.face >= 0) {
+                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = s.z + h.t * d.z;
+                } else {
+                    o[0] = inf; o[1] = inf; o[2] = inf;
+                }
+            }
+            if (lr == 0) {
+                st3(pos_w + 3 * (int64_t)e, pos);
+                st4(quat_w + 4 * (int64_t)e, q);
+                if (ts_last) ts_last[e] = ts[e];
+                if (outdated) outdated[e] = 0;
+            }
+        }
+    }
+}
+
+// The height-scan case of k_raycaster_update: yaw-only attachment and a pattern whose directions are all (0, 0, -c),
+// on a mesh with cell records.  One env per 192/256-thread slot as above; the sensor pose is rotated once per env by
+// its first lanes and shared through LDS.
+template <int BATCH>
+__global__ void __launch_bounds__(256)
+k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w, const float* __restrict__ pose,
+                        int ld_pose, const float* __restrict__ drift, const float* __restrict__ starts_l,
+                        const float* __restrict__ dirs_l, float max_dist, float* __restrict__ pos_w,
+                        float* __restrict__ quat_w, float* __restrict__ hits, const float* __restrict__ ts,
+                        float* __restrict__ ts_last, uint8_t* __restrict__ outdated) {
+    const float inf = __builtin_inff();
+    int le = threadIdx.x / slot_w;
+    int lr = threadIdx.x - le * slot_w;
+    for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
+        int e = base + le;
+        bool active = le < epb && e < N;
+        bool od = active && (outdated ? outdated[e] != 0 : true);
+        __syncthreads();
+        if (od) {
+            const float* p = pose + (int64_t)e * ld_pose;
+            V3 pos = ld3(p);
+            if (drift) { pos.x += drift[3 * e]; pos.y += drift[3 * e + 1]; pos.z += drift[3 * e + 2]; }
+            Q4 q = ld4(p + 3);
+            Q4 qr = yaw_quat(q);
+            for (int r = lr; r < R; r += slot_w) {
+                V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
+                s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
+                V3 d = ld3(dirs_l + 3 * r);
+                mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
+                mdp_hit_t h = mdp_rc_grid_down<BATCH>(&mesh, &ray, max_dist);
                 float* o = hits + ((int64_t)e * R + r) * 3;
                 if (h.face >= 0) {
                     o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = s.z + h.t * d.z;
@@ -453,18 +518,22 @@ extern "C" int mdp_raycast(const mdp_mesh_t* mesh, int64_t num_rays, const float
     MDP_REQUIRE(accel >= 0 && accel <= 3, "bad accel");
     if (num_rays == 0) return MDP_OK;
     int a = accel == 0 ? mesh->view.accel : (accel == 3 ? 0 : accel);  // 3 = brute force (tests)
-    hipLaunchKernelGGL(k_raycast, dim3(grid_for(num_rays, 128, 1 << 20)), dim3(128), 0, as_stream(stream),
-                       mesh->view, num_rays, ray_starts, ray_dirs, max_dist, ray_hits, ray_dist, ray_normal,
-                       ray_face_id, a);
+#define RC_LAUNCH(A)                                                                                              \
+    hipLaunchKernelGGL(k_raycast<A>, dim3(grid_for(num_rays, 128, 1 << 20)), dim3(128), 0, as_stream(stream),     \
+                       mesh->view, num_rays, ray_starts, ray_dirs, max_dist, ray_hits, ray_dist, ray_normal,       \
+                       ray_face_id)
+    if (a == 2) RC_LAUNCH(2); else if (a == 1) RC_LAUNCH(1); else RC_LAUNCH(0);
+#undef RC_LAUNCH
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
 
 extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int num_rays, const float* root_pose,
                                     int ld_pose, const float* drift, const float* ray_starts_local,
-                                    const float* ray_dirs_local, int attach_yaw_only, float max_dist, float* pos_w,
-                                    float* quat_w, float* ray_hits_w, const float* timestamp,
-                                    float* timestamp_last_update, uint8_t* is_outdated, void* stream) {
+                                    const float* ray_dirs_local, int attach_yaw_only, int pattern_vertical_down,
+                                    float max_dist, float* pos_w, float* quat_w, float* ray_hits_w,
+                                    const float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
+                                    void* stream) {
     MDP_REQUIRE(mesh && root_pose && ray_starts_local && ray_dirs_local && pos_w && quat_w && ray_hits_w,
                 "null pointer");
     MDP_REQUIRE(ld_pose >= 7, "root_pose must be (N,>=7)");
@@ -474,10 +543,25 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     int slot_w = num_rays >= 256 ? 256 : num_rays;
     int threads = ((epb * slot_w + 63) / 64) * 64;
     int64_t blocks = ((int64_t)num_envs + epb - 1) / epb;
-    hipLaunchKernelGGL(k_raycaster_update, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0, as_stream(stream),
-                       mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift, ray_starts_local,
-                       ray_dirs_local, attach_yaw_only, max_dist, pos_w, quat_w, ray_hits_w, timestamp,
-                       timestamp_last_update, is_outdated);
+    if (pattern_vertical_down && attach_yaw_only && mesh->view.accel == 1 && mesh->view.cell_recs) {
+        static const int batch = [] { const char* b = std::getenv("MDP_RC_BATCH"); return b ? std::atoi(b) : 2; }();
+#define RCD_LAUNCH(B)                                                                                             \
+    hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,          \
+                       as_stream(stream), mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift,  \
+                       ray_starts_local, ray_dirs_local, max_dist, pos_w, quat_w, ray_hits_w, timestamp,           \
+                       timestamp_last_update, is_outdated)
+        if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
+#undef RCD_LAUNCH
+        MDP_LAUNCH_CHECK();
+        return MDP_OK;
+    }
+#define RCU_LAUNCH(A)                                                                                             \
+    hipLaunchKernelGGL(k_raycaster_update<A>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,               \
+                       as_stream(stream), mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift,  \
+                       ray_starts_local, ray_dirs_local, attach_yaw_only, max_dist, pos_w, quat_w, ray_hits_w,     \
+                       timestamp, timestamp_last_update, is_outdated)
+    if (mesh->view.accel == 2) RCU_LAUNCH(2); else if (mesh->view.accel == 1) RCU_LAUNCH(1); else RCU_LAUNCH(0);
+#undef RCU_LAUNCH
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -165,7 +165,10 @@ MDP_RC_FN void mdp_rc_consider_rec(const mdp_ray_t* r, const mdp_rec_t* rec, mdp
     }
 }
 
-// All records of one cell.  Loads are issued four records at a time (independent of the running best hit)
+#ifndef MDP_RC_BATCH
+#define MDP_RC_BATCH 4
+#endif
+// All records of one cell.  Loads are issued MDP_RC_BATCH records at a time (independent of the running best hit)
 // so a lane has 12 x 128-bit loads in flight instead of one dependent round trip per triangle.
 MDP_RC_FN void mdp_rc_cell_recs(const mdp_mesh_view_t* m, const mdp_ray_t* r, int32_t b, int32_t e, mdp_hit_t* best) {
     // records are sorted by descending zmax: on a downward ray a triangle lying entirely below the current best
@@ -173,13 +176,13 @@ MDP_RC_FN void mdp_rc_cell_recs(const mdp_mesh_view_t* m, const mdp_ray_t* r, in
     const int down = r->dz < 0.0f;
     const float inv_dz = down ? 1.0f / r->dz : 0.0f;
     int stop = 0;
-    for (int32_t k = b; k < e && !stop; k += 4) {
-        mdp_rec_t R[4];
-        for (int i = 0; i < 4; ++i) {
+    for (int32_t k = b; k < e && !stop; k += MDP_RC_BATCH) {
+        mdp_rec_t R[MDP_RC_BATCH];
+        for (int i = 0; i < MDP_RC_BATCH; ++i) {
             int32_t kk = k + i < e ? k + i : e - 1;
             R[i] = mdp_rc_load_rec(m->cell_recs + 12 * (int64_t)kk);
         }
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < MDP_RC_BATCH; ++i) {
             if (k + i >= e || stop) continue;
             if (down && best->face >= 0) {
                 float t_reach = (R[i].v[10] - r->oz) * inv_dz;  // parameter at which the ray reaches zmax
@@ -262,6 +265,109 @@ MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, fl
     }
     return best;
 }
+
+#ifndef MDP_RC_HOST
+// ---- vertical downward rays (the height scan: pattern direction (0,0,-c), yaw-only attachment) -------------------
+// Same expression trees as mdp_rc_make_ray / mdp_rc_intersect / mdp_rc_grid for d = (0, 0, dz < 0): there kz = 2 and,
+// because d[kz] < 0, (kx, ky) = (1, 0); Sx = dy / dz and Sy = dx / dz are kept as computed values (-0.0f) so every
+// intermediate is bit-identical to the generic path (which the CPU oracle runs).  With the permutation a compile-time
+// constant the component selects vanish, and a vertical ray crosses exactly one xy cell: no DDA state.  The kernel
+// built on this needs about half the registers of the generic one (twice the waves per SIMD on a latency-bound walk).
+typedef struct { float ox, oy, oz, Sx, Sy, Sz, dz; } mdp_vray_t;
+
+__device__ __forceinline__ mdp_vray_t mdp_rc_make_vray(float ox, float oy, float oz, float dx, float dy, float dz) {
+    mdp_vray_t r;
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dz = dz;
+    r.Sx = dy / dz;   // comp(d, kx = 1) / d[kz]
+    r.Sy = dx / dz;   // comp(d, ky = 0) / d[kz]
+    r.Sz = 1.0f / dz;
+    return r;
+}
+
+__device__ __forceinline__ int mdp_rc_intersect_down(const mdp_vray_t* r, const float* tv, float* t_out) {
+    float Ax3 = tv[0] - r->ox, Ay3 = tv[1] - r->oy, Az3 = tv[2] - r->oz;
+    float Bx3 = tv[3] - r->ox, By3 = tv[4] - r->oy, Bz3 = tv[5] - r->oz;
+    float Cx3 = tv[6] - r->ox, Cy3 = tv[7] - r->oy, Cz3 = tv[8] - r->oz;
+    float Ax = Ay3 - r->Sx * Az3, Ay = Ax3 - r->Sy * Az3;
+    float Bx = By3 - r->Sx * Bz3, By = Bx3 - r->Sy * Bz3;
+    float Cx = Cy3 - r->Sx * Cz3, Cy = Cx3 - r->Sy * Cz3;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) return 0;
+    float det = (U + V) + W;
+    if (det == 0.0f) return 0;
+    float Az = r->Sz * Az3, Bz = r->Sz * Bz3, Cz = r->Sz * Cz3;
+    float T = (U * Az + V * Bz) + W * Cz;
+    if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) return 0;
+    float rcp = 1.0f / det;
+    *t_out = T * rcp;
+    return 1;
+}
+
+template <int BATCH>
+__device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, const mdp_vray_t* r, float max_t) {
+    mdp_hit_t best; best.t = max_t; best.face = -1;
+    // clip of mdp_rc_grid with d.x == d.y == 0: the xy axes only test the origin, z gives [t0, t1]
+    float pad = 1e-3f * m->cell + 1e-6f;
+    float hix = m->gx0 + m->cell * (float)m->ncx, hiy = m->gy0 + m->cell * (float)m->ncy;
+    if (r->ox < m->gx0 - pad || r->ox > hix + pad) return best;
+    if (r->oy < m->gy0 - pad || r->oy > hiy + pad) return best;
+    float t0 = 0.0f, t1 = max_t;
+    {
+        float l = m->zmin - pad, h = m->zmax + pad;
+        float inv = 1.0f / r->dz;
+        float ta = (l - r->oz) * inv, tb = (h - r->oz) * inv;
+        if (ta > tb) { float tmp = ta; ta = tb; tb = tmp; }
+        ta -= fabsf(ta) * 1e-5f + 1e-6f;
+        tb += fabsf(tb) * 1e-5f + 1e-6f;
+        if (ta > t0) t0 = ta;
+        if (tb < t1) t1 = tb;
+    }
+    if (t0 > t1) return best;
+    int cx = (int)floorf((r->ox - m->gx0) * m->inv_cell);
+    int cy = (int)floorf((r->oy - m->gy0) * m->inv_cell);
+    if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
+    if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
+    int32_t c = cy * m->ncx + cx;
+    int32_t b = m->cell_start[c], e = m->cell_start[c + 1];
+    const float inv_dz = 1.0f / r->dz;
+    int stop = 0;
+    for (int32_t k = b; k < e && !stop; k += BATCH) {
+        mdp_rec_t R[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            int32_t kk = k + i < e ? k + i : e - 1;
+            R[i] = mdp_rc_load_rec(m->cell_recs + 12 * (int64_t)kk);
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            if (k + i >= e || stop) continue;
+            if (best.face >= 0) {
+                float t_reach = (R[i].v[10] - r->oz) * inv_dz;
+                if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = 1; continue; }
+            }
+            int32_t f = mdp_rc_rec_face(&R[i]);
+            float t;
+            if (mdp_rc_intersect_down(r, R[i].v, &t)) {
+                if (t >= 0.0f && (t < best.t || (t == best.t && f < best.face && best.face >= 0))) {
+                    best.t = t;
+                    best.face = f;
+                }
+            }
+        }
+    }
+    return best;
+}
+#endif  // !MDP_RC_HOST
 
 // ---- BVH (binary, built on the host; stack traversal) -----------------------------------------
 // one axis of the slab test.  A direction component that is exactly 0 constrains nothing as long as the

@@ -10,12 +10,17 @@ from conftest import assert_close, to_np
 pytestmark = pytest.mark.gpu
 
 
-def run_env(name, n, steps, device, seed, **kw):
+def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, **kw):
     import torch
 
     from isaaclab_amd.envs.synthetic import make_velocity_env
 
     env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=seed, **kw)
+    if fuse_cast is not None:
+        env.scene.sensors["height_scanner"].fuse_into_observations = fuse_cast
+    if not fused:      # the per-entity / per-manager launches of the reference call structure
+        env.scene.fused_update = False
+        env.fuse_post_physics = False
     outs = []
     for t in range(steps):
         rec.feed(t)
@@ -43,12 +48,14 @@ def test_anymal_d_flat(device, n):
     compare(outs, replay_oracle(rec, 6))
 
 
-@pytest.mark.parametrize("n", (5, 128))
-def test_anymal_d_rough(device, n):
-    """BASELINE config C2 (rough, 187-ray height scan fused into the observation kernel, 235-dim observation)."""
+@pytest.mark.parametrize("n,fuse_cast,fused", ((5, False, True), (128, False, True), (128, True, True), (37, False, False)))
+def test_anymal_d_rough(device, n, fuse_cast, fused):
+    """BASELINE config C2 (rough, 187-ray height scan, 235-dim observation): the default launch structure (fused
+    scene update, fused termination + reward, vertical-ray cast kernel + lean observation kernel), the height scan
+    cast inside the observation kernel, and the unfused per-entity / per-manager launches."""
     from oracle.harness import replay_oracle
 
-    env, rec, outs = run_env("anymal_d_rough", n, 6, device, seed=12, small_terrain=True)
+    env, rec, outs = run_env("anymal_d_rough", n, 6, device, seed=12, small_terrain=True, fuse_cast=fuse_cast, fused=fused)
     assert outs[0][0].shape == (n, 235)
     compare(outs, replay_oracle(rec, 6))
     # sensor state after the run.  The rays themselves come from quat_apply_yaw on device vs host libm (1-ulp
