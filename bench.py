@@ -50,13 +50,15 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=24)
     p.add_argument("--stats-every", type=int, default=24, help="rollout length between episode-stat all-reduces")
     p.add_argument("--small-terrain", action="store_true")
-    p.add_argument("--no-fuse-cast", action="store_true", help="cast the height scan in its own kernel")
+    p.add_argument("--fuse-cast", action="store_true", help="cast the height scan inside the observation kernel")
     return p.parse_args()
 
 
 # ---- algorithmic bytes (SURVEY.md 8d counting rules; table repeated in DESIGN.md) -------------------------
 def algorithmic_bytes(env) -> dict:
-    """Per-env algorithmic HBM bytes of each kernel of one env-step and the launches per env-step."""
+    """Per-env algorithmic HBM bytes of each launch of one env-step and the launches per env-step
+    (fp32 = 4 B; every distinct per-env input read once, every output written once; constants, mesh, weights and
+    the generator excluded)."""
     robot = env.scene["robot"]
     J = robot.num_joints
     D = env.cfg.decimation
@@ -72,17 +74,23 @@ def algorithmic_bytes(env) -> dict:
             layers, _, hidden = act.sea_hidden_state.shape
             lstm_state_bytes = 2 * (2 * layers * hidden) * 4
     table = {
-        # name: (bytes per env per launch, launches per env-step)
+        # name: (bytes per env per launch, launches per env-step, kernel-name fragment in the rocprof traces)
         # PD family: read target,q,qd; write computed,applied.  LSTM net: + (h, c) of every layer read and written
-        "actuator": (20 * J + lstm_state_bytes * J, D),
-        "joint_acc": (12 * J, D),                              # read qd, RMW prev_qd, write acc
-        "contact_update": (44 * Bc, D),                        # read force, RMW 4 timers (+history shift)
-        "action": (16 * J, 1),                                 # read raw, RMW action/prev_action, write target
-        "termination": (4 * (3 * H * 1 + 2) + Tt + 2, 1),      # base contact history, episode length; flags
-        "reward": (4 * (13 + 4 * J + 3 + 3 * H * Bc + 2 * Bf + J) + 12 * Tr + 4, 1),
-        "command": (4 * 13 + 16 + 12, 1),                      # root state; command RMW; timers
-        "observation": (4 * (13 + 3 * J + 3) + 4 * O + 12 * R + 28, 1),  # state in; obs + ray_hits + sensor pose out
+        "actuator": (20 * J + lstm_state_bytes * J, D, "k_lstm" if lstm_state_bytes else "k_actuator_pd"),
+        # fused scene.update: joint_acc (read qd, RMW prev_qd, write acc) + contact sensor (read force, RMW 4 timers,
+        # history shift) + root_state_w assembly (13 floats in, 13 out)
+        "scene_update": (12 * J + 44 * Bc + 104, D, "k_scene_update"),
+        "action": (16 * J, 1, "k_joint_action"),               # read raw, RMW action/prev_action, write target
+        # episode counter RMW + terminations (base contact history, flags) + rewards (state in; sums / step out)
+        "term_reward": (16 + 4 * (3 * H * 1) + Tt + 2 + 4 * (13 + 4 * J + 3 + 3 * H * Bc + 2 * Bf + J) + 12 * Tr + 4, 1,
+                        "k_term_reward"),
+        "command": (4 * 13 + 16 + 12, 1, "k_velocity_command"),  # root state; command RMW; timers
     }
+    if R:
+        table["raycast"] = (4 * 7 + 12 * R + 28, 1, "k_raycaster_update")  # pose in; ray_hits + sensor pose out
+        table["observation"] = (4 * (13 + 3 * J + 3) + 4 * R + 4 * O, 1, "k_obs")  # state + hit heights in; obs out
+    else:
+        table["observation"] = (4 * (13 + 3 * J + 3) + 4 * O, 1, "k_obs")
     return table
 
 
@@ -107,8 +115,8 @@ def main():
     env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
                                  small_terrain=args.small_terrain, inject_random=False)
     env.observation_manager.persistent_output = True
-    if args.no_fuse_cast and "height_scanner" in env.scene.sensors:
-        env.scene.sensors["height_scanner"].fuse_into_observations = False
+    if "height_scanner" in env.scene.sensors:
+        env.scene.sensors["height_scanner"].fuse_into_observations = args.fuse_cast
     # episode_length_buf ~ U{0..999}
     g = torch.Generator().manual_seed(99 + rank)
     env.episode_length_buf.copy_(torch.randint(0, 1000, (args.envs,), generator=g))
@@ -207,56 +215,82 @@ def main():
         dist.destroy_process_group()
 
 
-def _time_launches(fn, pre, reps: int) -> float:
-    """Average duration (s) of ``fn`` measured with HIP events on torch's current stream (the launch stream)."""
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-    for i in range(3):
-        pre()
+def _graph_time(fn, reps: int = 20, replays: int = 10) -> float:
+    """Average duration (s) of ``fn`` -- one stage of the step, one kernel launch -- measured with HIP events on
+    torch's current stream (the stream every launch goes to) around replays of a hipGraph holding ``reps`` copies of the
+    launch: kernel time plus the graph's launch gap, no Python / ctypes time."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         fn()
+    torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    for i in range(reps):
-        pre()
-        starts[i].record()
-        fn()
-        stops[i].record()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
-    ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
-    ms = ms[: max(1, int(len(ms) * 0.9))]          # drop the slowest 10 % (scheduler noise)
-    return 1e-3 * sum(ms) / len(ms)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(replays):
+        g.replay()
+    e.record()
+    torch.cuda.synchronize()
+    return 1e-3 * s.elapsed_time(e) / (reps * replays)
+
+
+def _pmc_traffic(kernel_fragment: str):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, made by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command).  Counters are in KiB;
+    FETCH_SIZE is doubled (gfx950 counts 64 B per 128-B request, MI355X_MICROARCH.md section HBM; checked on k_lstm,
+    whose compulsory reads are known)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    for name, row in table.get("kernels", {}).items():
+        if kernel_fragment in name and "FETCH_SIZE" in row and "WRITE_SIZE" in row:
+            return (2.0 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024.0
+    return None
 
 
 def measure_roofline(env, args) -> dict:
-    """Times each kernel of the step in isolation and reports the one with the largest share of the step."""
+    """Times every launch of the step in isolation and reports the one with the largest share of the step."""
     table = algorithmic_bytes(env)
     N = env.num_envs
     robot = env.scene["robot"]
     sensors = env.scene.sensors
     fns = {
-        "actuator": (lambda: robot.write_data_to_sim(), lambda: None),
-        "contact_update": (lambda: sensors["contact_forces"].update(env.physics_dt), lambda: None),
-        "termination": (lambda: env.termination_manager.compute(), lambda: None),
-        "reward": (lambda: env.reward_manager.compute(dt=env.step_dt), lambda: None),
-        "command": (lambda: env.command_manager.compute(dt=env.step_dt), lambda: None),
+        "actuator": lambda: robot.write_data_to_sim(),
+        "scene_update": lambda: env.scene.update(env.physics_dt),
+        "action": lambda: env.action_manager.process_action(env.action_manager.action),
+        "term_reward": lambda: env._termination_reward_fused(),
+        "command": lambda: env.command_manager.compute(dt=env.step_dt),
+        "observation": lambda: env.observation_manager.compute(),
     }
+    fill_s = 0.0
     if "height_scanner" in sensors:
         hs = sensors["height_scanner"]
-        # every timed launch must cast: age the sensor by one update period first
-        fns["observation"] = (lambda: env.observation_manager.compute(),
-                              lambda: hs.update(env.step_dt))
-    else:
-        fns["observation"] = (lambda: env.observation_manager.compute(), lambda: None)
+
+        def cast():                     # every timed launch must cast: re-arm the outdated flags first
+            hs._is_outdated.fill_(True)
+            hs._update_outdated_buffers()
+
+        fill_s = _graph_time(lambda: hs._is_outdated.fill_(True))
+        fns["raycast"] = cast
     per_kernel = {}
-    for name, (fn, pre) in fns.items():
-        dur = _time_launches(fn, pre, 60)
-        nbytes, launches = table[name]
-        per_kernel[name] = {"us": 1e6 * dur, "launches_per_step": launches, "alg_bytes_per_env": nbytes,
-                            "GBps": nbytes * N / dur / 1e9}
+    for name, fn in fns.items():
+        dur = _graph_time(fn) - (fill_s if name == "raycast" else 0.0)
+        nbytes, launches, frag = table[name]
+        per_kernel[name] = {"kernel": frag, "us": 1e6 * dur, "launches_per_step": launches,
+                            "alg_bytes_per_env": nbytes, "GBps": nbytes * N / dur / 1e9}
     dom = max(per_kernel, key=lambda k: per_kernel[k]["us"] * per_kernel[k]["launches_per_step"])
     d = per_kernel[dom]
-    total_alg = sum(b * l for b, l in table.values())
-    return {"bound": "hbm", "kernel": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": None,
+    total_alg = sum(b * l for b, l, _ in table.values())
+    return {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(d["kernel"]),
             "alg_bytes_per_launch": d["alg_bytes_per_env"] * N, "avg_launch_us": d["us"],
             "alg_bytes_per_env_step": total_alg, "kernels": per_kernel}
 
