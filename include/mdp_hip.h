@@ -222,6 +222,29 @@ typedef struct {
 } mdp_scene_update_t;
 int mdp_scene_update(const mdp_scene_update_t* desc, float dt, void* stream);
 
+/* scene.update(k) and write_data_to_sim(k+1) have no physics step between them (manager_based_rl_env.py:184-195:
+ * the loop body is apply_action, write_data_to_sim, sim.step, scene.update), so the actuator launch of sub-step k+1
+ * can carry the scene update of sub-step k along: extra blocks of the SAME launch run mdp_scene_update(update, dt)
+ * while the actuator blocks run mdp_actuator_{pd,lstm}_compute (articulation.py:1399-1436).  joint_pos / joint_vel
+ * must then be the physics buffers of the current frame (update->joint_pos_src / joint_vel_src), not the state
+ * container's copies, which the update blocks are writing.  update == NULL is the plain actuator call. */
+int mdp_actuator_pd_compute_after_update(const mdp_scene_update_t* update, float dt, int kind, int num_envs,
+                                         int num_joints, const float* q_des, int ld_q_des,
+                                         const float* qd_des, int ld_qd_des, const float* tau_ff, int ld_tau_ff,
+                                         const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                         const float* stiffness, const float* damping,
+                                         const float* effort_limit, const float* velocity_limit,
+                                         float saturation_effort, float* computed_effort, float* applied_effort,
+                                         void* stream);
+int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* update, float dt,
+                                           const mdp_net_desc_t* desc, const float* packed_weights,
+                                           int num_envs, int num_joints, const float* q_des, int ld_q_des,
+                                           const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                           float* hidden_state, float* cell_state,
+                                           const float* effort_limit, const float* velocity_limit,
+                                           float saturation_effort, float* computed_effort, float* applied_effort,
+                                           void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Ray casting (LAB/utils/warp/ops.py:24-145, kernels.py:13-75; LAB/sensors/ray_caster/ray_caster.py:220-260)
  * ------------------------------------------------------------------------------------------ */

@@ -5,6 +5,8 @@ from __future__ import annotations
 from abc import ABC, abstractmethod
 from collections.abc import Sequence
 
+import ctypes as C
+
 import torch
 
 from .. import _lib as L
@@ -108,6 +110,11 @@ class ActuatorBase(ABC):
         return param
 
     # -- shared launcher ---------------------------------------------------------------------------
+    #: whether ``compute`` issues exactly one launch that can carry a pending scene update along
+    #: (``mdp_actuator_*_compute_after_update``); set by ``Articulation`` right before ``compute``
+    carries_scene_update: bool = False
+    pending_scene_update = None
+
     def _pd_launch(self, kind: str, control_action: ArticulationActions, joint_pos: torch.Tensor,
                    joint_vel: torch.Tensor, saturation: float = torch.inf):
         """One fused kernel: PD law + saturation model, writes ``computed_effort`` / ``applied_effort``
@@ -130,7 +137,10 @@ class ActuatorBase(ABC):
             p = getattr(self, name)
             if not p.is_contiguous():
                 setattr(self, name, p.contiguous())
-        L.check(L.lib.mdp_actuator_pd_compute(
+        # a pending scene update (scene.update of the frame being read) rides along in the same launch
+        upd, self.pending_scene_update = self.pending_scene_update, None
+        L.check(L.lib.mdp_actuator_pd_compute_after_update(
+            C.byref(upd[0]) if upd is not None else None, float(upd[1]) if upd is not None else 0.0,
             L.ACT_KINDS[kind], self._num_envs, self.num_joints, *args, q.data_ptr(), ld_q, qd.data_ptr(), ld_qd,
             self.stiffness.data_ptr(), self.damping.data_ptr(), self.effort_limit.data_ptr(),
             self.velocity_limit.data_ptr(), float(saturation), self.computed_effort.data_ptr(),

@@ -118,7 +118,9 @@ class ActuatorNetLSTM(DCMotor):
         q, ld_q = L.rows(joint_pos, "joint_pos")
         qd, ld_qd = L.rows(joint_vel, "joint_vel")
         des, ld_des = L.rows(control_action.joint_positions, "joint_positions")
-        L.check(L.lib.mdp_actuator_lstm_compute(
+        upd, self.pending_scene_update = self.pending_scene_update, None
+        L.check(L.lib.mdp_actuator_lstm_compute_after_update(
+            C.byref(upd[0]) if upd is not None else None, float(upd[1]) if upd is not None else 0.0,
             C.byref(self._net.desc), self._net.packed.data_ptr(), self._num_envs, self.num_joints,
             des.data_ptr(), ld_des, q.data_ptr(), ld_q, qd.data_ptr(), ld_qd,
             self.sea_hidden_state.data_ptr(), self.sea_cell_state.data_ptr(),
@@ -132,6 +134,8 @@ class ActuatorNetLSTM(DCMotor):
 
 class ActuatorNetMLP(DCMotor):
     """actuator_net.py:102-188"""
+
+    carries_scene_update = False   # own kernel (history shift): the update is launched separately
 
     def __init__(self, cfg, *args, **kwargs):
         super().__init__(cfg, *args, **kwargs)

@@ -13,6 +13,8 @@ from .actuator_base import ActuatorBase
 class ImplicitActuator(ActuatorBase):
     """actuator_pd.py:32-87: returns the action unchanged, stores the approximate torques."""
 
+    carries_scene_update = True
+
     def reset(self, *args, **kwargs):
         pass
 
@@ -23,6 +25,8 @@ class ImplicitActuator(ActuatorBase):
 
 class IdealPDActuator(ActuatorBase):
     """actuator_pd.py:95-145"""
+
+    carries_scene_update = True
 
     def reset(self, env_ids: Sequence[int]):
         pass

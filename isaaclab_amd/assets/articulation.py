@@ -80,9 +80,16 @@ class Articulation:
         for actuator in self.actuators.values():
             actuator.reset(env_ids)
 
-    def write_data_to_sim(self):
-        """articulation.py:172-199 (the physics-side setters are out of scope)."""
-        self._apply_actuator_model()
+    def write_data_to_sim(self, carry_update=None):
+        """articulation.py:172-199 (the physics-side setters are out of scope).  ``carry_update = (desc, dt)`` lets the
+        actuator launch run the scene update of the frame it reads in the same kernel (``can_carry_update``)."""
+        self._apply_actuator_model(carry_update)
+
+    @property
+    def can_carry_update(self) -> bool:
+        if not getattr(self, "_single_full_group", False):
+            return False
+        return bool(next(iter(self.actuators.values())).carries_scene_update)
 
     def update(self, dt: float):
         self._data.update(dt)
@@ -174,16 +181,23 @@ class Articulation:
                 return
         self._single_full_group = False
 
-    def _apply_actuator_model(self):
+    def _apply_actuator_model(self, carry_update=None):
         """articulation.py:1399-1436"""
         d = self._data
+        if carry_update is not None:
+            # the launch that refreshes d.joint_pos / d.joint_vel is this very launch: read the physics buffers
+            joint_pos_all = self.root_physx_view.get_dof_positions()
+            joint_vel_all = self.root_physx_view.get_dof_velocities()
+        else:
+            joint_pos_all, joint_vel_all = d.joint_pos, d.joint_vel
         for actuator in self.actuators.values():
             ji = actuator.joint_indices
+            actuator.pending_scene_update = carry_update
             control_action = ArticulationActions(
                 joint_positions=d.joint_pos_target[:, ji], joint_velocities=d.joint_vel_target[:, ji],
                 joint_efforts=d.joint_effort_target[:, ji], joint_indices=ji,
             )
-            control_action = actuator.compute(control_action, joint_pos=d.joint_pos[:, ji], joint_vel=d.joint_vel[:, ji])
+            control_action = actuator.compute(control_action, joint_pos=joint_pos_all[:, ji], joint_vel=joint_vel_all[:, ji])
             if self._single_full_group:
                 # outputs already live in the data buffers; targets handed to physics are aliases
                 if control_action.joint_efforts is not None:

@@ -14,6 +14,7 @@
 // (SURVEY.md section 8d); the MFMA pipe is there to keep the VALU free for the gate transcendentals.
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
+#include "scene_update_device.hpp"
 
 #include <vector>
 
@@ -153,21 +154,27 @@ MDP_DEV void dc_clip_store(float tau, float qd, int64_t row, const float* __rest
     applied[row] = tclamp(tau, mn, mx);
 }
 
+// Blocks >= nb_act carry the scene update of the frame this launch reads (see k_actuator_pd).
 template <int H>
 __global__ void __launch_bounds__(256)
-k_lstm(NetDev net, const float* __restrict__ packed, int64_t rows, int J,
+k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
+       NetDev net, const float* __restrict__ packed, int64_t rows, int J,
        const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
        const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
        const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
        float* __restrict__ computed, float* __restrict__ applied) {
     constexpr int TPL = H / 4;
     extern __shared__ float lds[];
+    if (blockIdx.x >= nb_act) {
+        scene_update_block(upd, dt, blockIdx.x - nb_act, nb_root, nb_joint, nb_contact);
+        return;
+    }
     for (int i = threadIdx.x; i < net.L.total; i += blockDim.x) lds[i] = packed[i];
     __syncthreads();
     int lane = threadIdx.x & 63;
     int gq = lane >> 4, col = lane & 15;
     int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    int64_t nwaves = (int64_t)nb_act * (blockDim.x >> 6);
     int64_t ngroups = (rows + 15) / 16;
     for (int64_t g = wave; g < ngroups; g += nwaves) {
         int64_t row = g * 16 + col;
@@ -381,35 +388,49 @@ static unsigned net_grid(int64_t rows) {
     return (unsigned)blocks;
 }
 
-extern "C" int mdp_actuator_lstm_compute(const mdp_net_desc_t* desc, const float* packed_weights, int num_envs,
-                                         int num_joints, const float* q_des, int ld_q_des, const float* joint_pos,
-                                         int ld_pos, const float* joint_vel, int ld_vel, float* hidden_state,
-                                         float* cell_state, const float* effort_limit, const float* velocity_limit,
-                                         float saturation_effort, float* computed_effort, float* applied_effort,
-                                         void* stream) {
+extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* update, float dt,
+                                                      const mdp_net_desc_t* desc, const float* packed_weights,
+                                                      int num_envs, int num_joints, const float* q_des, int ld_q_des,
+                                                      const float* joint_pos, int ld_pos, const float* joint_vel,
+                                                      int ld_vel, float* hidden_state, float* cell_state,
+                                                      const float* effort_limit, const float* velocity_limit,
+                                                      float saturation_effort, float* computed_effort,
+                                                      float* applied_effort, void* stream) {
     int rc = validate(desc);
     if (rc != MDP_OK) return rc;
     MDP_REQUIRE(desc->lstm_layers >= 1, "not an LSTM network");
     MDP_REQUIRE(packed_weights && q_des && joint_pos && joint_vel && hidden_state && cell_state && effort_limit &&
                     velocity_limit && computed_effort && applied_effort,
                 "null pointer");
+    SceneUpdatePlan plan;
+    if (update) {
+        rc = scene_update_plan(update, &plan);
+        if (rc != MDP_OK) return rc;
+    } else {
+        std::memset(&plan.d, 0, sizeof(plan.d));
+    }
     int64_t rows = (int64_t)num_envs * num_joints;
-    if (rows == 0) return MDP_OK;
+    if (rows == 0) {
+        if (update) return mdp_scene_update(update, dt, stream);
+        return MDP_OK;
+    }
     NetDev net;
     net.d = *desc;
     make_layout(*desc, net.L);
     size_t lds_bytes = (size_t)net.L.total * sizeof(float);
     MDP_REQUIRE(lds_bytes <= 150 * 1024, "network too large for LDS staging (%zu bytes)", lds_bytes);
-    dim3 grid(net_grid(rows)), block(256);
+    unsigned nb_act = net_grid(rows);
+    dim3 grid(nb_act + plan.total), block(256);
     hipStream_t s = as_stream(stream);
 #define LAUNCH(HH)                                                                                                 \
     do {                                                                                                           \
         if (lds_bytes > 64 * 1024)                                                                                 \
             MDP_CHECK_HIP(hipFuncSetAttribute((const void*)k_lstm<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)lds_bytes));                                                    \
-        hipLaunchKernelGGL(k_lstm<HH>, grid, block, lds_bytes, s, net, packed_weights, rows, num_joints, q_des,    \
-                           ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, \
-                           velocity_limit, saturation_effort, computed_effort, applied_effort);                    \
+        hipLaunchKernelGGL(k_lstm<HH>, grid, block, lds_bytes, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint, \
+                           plan.nb_contact, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,     \
+                           ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,      \
+                           saturation_effort, computed_effort, applied_effort);                                    \
     } while (0)
     switch (desc->lstm_hidden) {
         case 8: LAUNCH(8); break;
@@ -420,6 +441,18 @@ extern "C" int mdp_actuator_lstm_compute(const mdp_net_desc_t* desc, const float
 #undef LAUNCH
     MDP_LAUNCH_CHECK();
     return MDP_OK;
+}
+
+extern "C" int mdp_actuator_lstm_compute(const mdp_net_desc_t* desc, const float* packed_weights, int num_envs,
+                                         int num_joints, const float* q_des, int ld_q_des, const float* joint_pos,
+                                         int ld_pos, const float* joint_vel, int ld_vel, float* hidden_state,
+                                         float* cell_state, const float* effort_limit, const float* velocity_limit,
+                                         float saturation_effort, float* computed_effort, float* applied_effort,
+                                         void* stream) {
+    return mdp_actuator_lstm_compute_after_update(nullptr, 0.0f, desc, packed_weights, num_envs, num_joints, q_des,
+                                                  ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state,
+                                                  cell_state, effort_limit, velocity_limit, saturation_effort,
+                                                  computed_effort, applied_effort, stream);
 }
 
 extern "C" int mdp_actuator_lstm_reset(int layers, int hidden, int num_envs, int num_joints, float* hidden_state,

@@ -2,6 +2,7 @@
 // Reference: LAB/actuators/actuator_pd.py, LAB/utils/buffers/*.py, LAB/utils/interpolation/*.py
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
+#include "scene_update_device.hpp"
 
 using namespace mdp;
 
@@ -9,8 +10,12 @@ namespace {
 
 // One thread per (env, joint) element, flat index -> perfectly coalesced on contiguous (N,J).
 // HBM-bound: reads q,qd,target(+gains), writes computed & applied.
+// Blocks >= nb_act carry the scene update of the frame this launch reads (scene.update(k) + write_data_to_sim(k+1) in one
+// launch; nb_act == gridDim.x when there is none).
 template <int KIND>
-__global__ void k_actuator_pd(int64_t total, int J,
+__global__ void __launch_bounds__(256)
+k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
+              int64_t total, int J,
                               const float* __restrict__ q_des, int ld_q_des,
                               const float* __restrict__ qd_des, int ld_qd_des,
                               const float* __restrict__ tau_ff, int ld_tau_ff,
@@ -19,8 +24,12 @@ __global__ void k_actuator_pd(int64_t total, int J,
                               const float* __restrict__ kp, const float* __restrict__ kd,
                               const float* __restrict__ eff_lim, const float* __restrict__ vel_lim,
                               float sat, float* __restrict__ computed, float* __restrict__ applied) {
+    if (blockIdx.x >= nb_act) {
+        scene_update_block(upd, dt, blockIdx.x - nb_act, nb_root, nb_joint, nb_contact);
+        return;
+    }
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
+         i += (int64_t)nb_act * blockDim.x) {
         int64_t e = i / J;
         int j = (int)(i - e * J);
         float qv = q[e * ld_q + j];
@@ -133,27 +142,40 @@ __global__ void k_linear_interp(const float* __restrict__ x, const float* __rest
 
 }  // namespace
 
-extern "C" int mdp_actuator_pd_compute(int kind, int num_envs, int num_joints,
-                                       const float* q_des, int ld_q_des, const float* qd_des, int ld_qd_des,
-                                       const float* tau_ff, int ld_tau_ff, const float* joint_pos, int ld_pos,
-                                       const float* joint_vel, int ld_vel, const float* stiffness,
-                                       const float* damping, const float* effort_limit,
-                                       const float* velocity_limit, float saturation_effort,
-                                       float* computed_effort, float* applied_effort, void* stream) {
+extern "C" int mdp_actuator_pd_compute_after_update(const mdp_scene_update_t* update, float dt, int kind, int num_envs,
+                                                    int num_joints, const float* q_des, int ld_q_des,
+                                                    const float* qd_des, int ld_qd_des, const float* tau_ff,
+                                                    int ld_tau_ff, const float* joint_pos, int ld_pos,
+                                                    const float* joint_vel, int ld_vel, const float* stiffness,
+                                                    const float* damping, const float* effort_limit,
+                                                    const float* velocity_limit, float saturation_effort,
+                                                    float* computed_effort, float* applied_effort, void* stream) {
     MDP_REQUIRE(num_envs >= 0 && num_joints >= 0, "negative shape (%d,%d)", num_envs, num_joints);
-    if (num_envs == 0 || num_joints == 0) return MDP_OK;
+    SceneUpdatePlan plan;
+    if (update) {
+        int rc = scene_update_plan(update, &plan);
+        if (rc != MDP_OK) return rc;
+    } else {
+        std::memset(&plan.d, 0, sizeof(plan.d));
+    }
+    if (num_envs == 0 || num_joints == 0) {
+        if (update) return mdp_scene_update(update, dt, stream);
+        return MDP_OK;
+    }
     MDP_REQUIRE(joint_pos && joint_vel && stiffness && damping && effort_limit && computed_effort && applied_effort,
                 "mdp_actuator_pd_compute: null required pointer");
     MDP_REQUIRE(ld_pos >= num_joints && ld_vel >= num_joints, "row stride smaller than num_joints");
     MDP_REQUIRE(kind != MDP_ACT_DC_MOTOR || velocity_limit, "DC motor needs velocity_limit");
     int64_t total = (int64_t)num_envs * num_joints;
     const int block = 256;
-    unsigned grid = grid_for(total, block);
+    unsigned nb_act = grid_for(total, block);
+    unsigned grid = nb_act + plan.total;
     hipStream_t s = as_stream(stream);
-#define LAUNCH(K)                                                                                             \
-    hipLaunchKernelGGL(k_actuator_pd<K>, dim3(grid), dim3(block), 0, s, total, num_joints, q_des, ld_q_des,  \
-                       qd_des, ld_qd_des, tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel, stiffness, \
-                       damping, effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort)
+#define LAUNCH(K)                                                                                              \
+    hipLaunchKernelGGL(k_actuator_pd<K>, dim3(grid), dim3(block), 0, s, plan.d, dt, nb_act, plan.nb_root,      \
+                       plan.nb_joint, plan.nb_contact, total, num_joints, q_des, ld_q_des, qd_des, ld_qd_des,   \
+                       tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel, stiffness, damping,             \
+                       effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort)
     switch (kind) {
         case MDP_ACT_IMPLICIT:
         case MDP_ACT_IDEAL_PD: LAUNCH(MDP_ACT_IDEAL_PD); break;
@@ -163,6 +185,19 @@ extern "C" int mdp_actuator_pd_compute(int kind, int num_envs, int num_joints,
 #undef LAUNCH
     MDP_LAUNCH_CHECK();
     return MDP_OK;
+}
+
+extern "C" int mdp_actuator_pd_compute(int kind, int num_envs, int num_joints,
+                                       const float* q_des, int ld_q_des, const float* qd_des, int ld_qd_des,
+                                       const float* tau_ff, int ld_tau_ff, const float* joint_pos, int ld_pos,
+                                       const float* joint_vel, int ld_vel, const float* stiffness,
+                                       const float* damping, const float* effort_limit,
+                                       const float* velocity_limit, float saturation_effort,
+                                       float* computed_effort, float* applied_effort, void* stream) {
+    return mdp_actuator_pd_compute_after_update(nullptr, 0.0f, kind, num_envs, num_joints, q_des, ld_q_des, qd_des,
+                                                ld_qd_des, tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel,
+                                                stiffness, damping, effort_limit, velocity_limit, saturation_effort,
+                                                computed_effort, applied_effort, stream);
 }
 
 extern "C" int mdp_circular_buffer_append(float* buffer, int64_t* num_pushes, int max_len, int num_envs, int dim,

@@ -1,0 +1,171 @@
+// Post-physics scene update as a block-level device routine (interactive_scene.py:496-513): shared by the stand-alone
+// launch (mdp_scene_update) and by the actuator kernels that carry the update of the frame they read along
+// (scene.update(k) and write_data_to_sim(k+1) have no physics step between them).
+#pragma once
+#include "mdp_device.hpp"
+#include "mdp_host.hpp"
+
+namespace mdp {
+
+__device__ __forceinline__ void contact_body_update(int64_t i, int e, int b, int B, int H,
+                                                    const float* __restrict__ forces, float* __restrict__ net,
+                                                    float* __restrict__ hist, float* __restrict__ last_air,
+                                                    float* __restrict__ cur_air, float* __restrict__ last_con,
+                                                    float* __restrict__ cur_con, float elapsed, float thresh) {
+    V3 f = ld3(forces + 3 * i);
+    st3(net + 3 * i, f);
+    if (hist && H > 0) {
+        // history[e, 1:] = history[e, :-1]; history[e, 0] = net  (contact_sensor.py:327-328)
+        float* hb = hist + ((int64_t)e * H * B + b) * 3;
+        for (int s = H - 1; s >= 1; --s) {
+            float* dst = hb + (int64_t)s * B * 3;
+            const float* src = hb + (int64_t)(s - 1) * B * 3;
+            dst[0] = src[0];
+            dst[1] = src[1];
+            dst[2] = src[2];
+        }
+        st3(hb, f);
+    }
+    if (cur_air) {
+        bool is_contact = norm3(f) > thresh;
+        float ca = cur_air[i], cc = cur_con[i];
+        bool first_contact = (ca > 0.0f) && is_contact;
+        bool first_detached = (cc > 0.0f) && !is_contact;
+        if (first_contact) last_air[i] = ca + elapsed;
+        cur_air[i] = !is_contact ? (ca + elapsed) : 0.0f;
+        if (first_detached) last_con[i] = cc + elapsed;
+        cur_con[i] = is_contact ? (cc + elapsed) : 0.0f;
+    }
+}
+
+
+// Blocks are split into four contiguous ranges, one per group:
+//   [0, nb_root)      root_state_w assembly, one thread per (env, column)
+//   [.., +nb_joint)   joint_pos / joint_vel refresh + joint_acc, one thread per (env, joint)
+//   [.., +nb_contact) contact sensor, a block owns 256 / B whole envs
+//   [.., +nb_tick)    lazily evaluated sensors, one thread per (sensor, env)
+// `b` is the block index within the update's range; blockDim.x must be 256.
+__device__ __forceinline__ void scene_update_block(const mdp_scene_update_t& d, float dt, unsigned b, unsigned nb_root,
+                                                   unsigned nb_joint, unsigned nb_contact) {
+    const int N = d.num_envs;
+    if (b < nb_root) {
+        int64_t i = (int64_t)b * 256 + threadIdx.x;
+        if (i >= (int64_t)N * 13) return;
+        int64_t r = i / 13;
+        int k = (int)(i - r * 13);
+        float v;
+        if (k < 3) v = d.root_transforms[7 * r + k];
+        else if (k == 3) v = d.root_transforms[7 * r + 6];
+        else if (k < 7) v = d.root_transforms[7 * r + k - 1];
+        else v = d.root_velocities[6 * r + (k - 7)];
+        d.root_state_w[i] = v;
+        return;
+    }
+    b -= nb_root;
+    if (b < nb_joint) {
+        int J = d.num_joints;
+        int64_t i = (int64_t)b * 256 + threadIdx.x;
+        if (i >= (int64_t)N * J) return;
+        int64_t e = i / J;
+        int j = (int)(i - e * J);
+        float qd = d.joint_vel_src[e * d.ld_joint_src + j];
+        if (d.joint_vel) d.joint_vel[i] = qd;
+        if (d.joint_pos) d.joint_pos[i] = d.joint_pos_src[e * d.ld_joint_src + j];
+        if (d.joint_acc) {
+            d.joint_acc[i] = (qd - d.prev_joint_vel[i]) / d.acc_elapsed;
+            d.prev_joint_vel[i] = qd;
+        }
+        return;
+    }
+    b -= nb_joint;
+    if (b < nb_contact) {
+        int B = d.num_contact_bodies;
+        int epb = 256 / B;
+        int le = threadIdx.x / B;
+        int bb = threadIdx.x - le * B;
+        int e = (int)b * epb + le;
+        bool active = (le < epb) && (e < N);
+        float t_new = 0.0f, t_last = 0.0f;
+        bool od = false;
+        if (active) {
+            t_new = d.contact_timestamp[e] + dt;
+            t_last = d.contact_timestamp_last_update[e];
+            od = (d.contact_is_outdated[e] != 0) || ((t_new - t_last) + 1e-6f >= d.contact_update_period);
+        }
+        __syncthreads();
+        if (active) {
+            if (od && d.contact_eager)
+                contact_body_update((int64_t)e * B + bb, e, bb, B, d.history_len, d.net_contact_forces, d.net_forces_w,
+                                    d.net_forces_w_history, d.last_air_time, d.current_air_time, d.last_contact_time,
+                                    d.current_contact_time, t_new - t_last, d.force_threshold);
+            if (bb == 0) {
+                d.contact_timestamp[e] = t_new;
+                if (od && d.contact_eager) {
+                    d.contact_timestamp_last_update[e] = t_new;
+                    od = false;
+                }
+                d.contact_is_outdated[e] = od ? 1 : 0;
+            }
+        }
+        return;
+    }
+    b -= nb_contact;
+    {
+        int64_t i = (int64_t)b * 256 + threadIdx.x;
+        if (i >= (int64_t)N * d.num_ticks) return;
+        int s = (int)(i / N);
+        int e = (int)(i - (int64_t)s * N);
+        float t = d.tick_timestamp[s][e] + dt;
+        d.tick_timestamp[s][e] = t;
+        if ((t - d.tick_timestamp_last_update[s][e]) + 1e-6f >= d.tick_update_period[s]) d.tick_is_outdated[s][e] = 1;
+    }
+}
+
+struct SceneUpdatePlan {
+    mdp_scene_update_t d;
+    unsigned nb_root = 0, nb_joint = 0, nb_contact = 0, nb_tick = 0, total = 0;
+};
+
+// validates a descriptor and sizes the block ranges (host)
+inline int scene_update_plan(const mdp_scene_update_t* desc, SceneUpdatePlan* plan) {
+    MDP_REQUIRE(desc, "null scene-update descriptor");
+    const mdp_scene_update_t& d = *desc;
+    MDP_REQUIRE(d.num_envs >= 0 && d.num_joints >= 0 && d.num_contact_bodies >= 0 && d.history_len >= 0, "negative size");
+    MDP_REQUIRE(d.num_ticks >= 0 && d.num_ticks <= 4, "at most 4 lazily evaluated sensors per launch (got %d)", d.num_ticks);
+    const int N = d.num_envs;
+    plan->d = d;
+    if (N == 0) return MDP_OK;
+    const bool has_root = d.root_state_w != nullptr;
+    const bool has_joint = d.joint_vel_src != nullptr && d.num_joints > 0;
+    const bool has_contact = d.net_contact_forces != nullptr && d.num_contact_bodies > 0;
+    if (has_root) MDP_REQUIRE(d.root_transforms && d.root_velocities, "root_state_w needs root_transforms and root_velocities");
+    if (has_joint) {
+        MDP_REQUIRE(d.ld_joint_src >= d.num_joints, "joint source row stride %d < %d joints", d.ld_joint_src, d.num_joints);
+        MDP_REQUIRE(!d.joint_pos || d.joint_pos_src, "joint_pos without a source");
+        MDP_REQUIRE(!d.joint_acc || (d.prev_joint_vel && d.acc_elapsed > 0.0f), "joint_acc needs prev_joint_vel and elapsed > 0");
+    }
+    if (has_contact) {
+        MDP_REQUIRE(d.num_contact_bodies <= 256, "fused scene update supports <= 256 contact bodies (got %d)", d.num_contact_bodies);
+        MDP_REQUIRE(d.net_forces_w && d.contact_timestamp && d.contact_timestamp_last_update && d.contact_is_outdated,
+                    "contact sensor buffers missing");
+        MDP_REQUIRE((d.current_air_time == nullptr && d.last_air_time == nullptr && d.last_contact_time == nullptr &&
+                     d.current_contact_time == nullptr) ||
+                        (d.current_air_time && d.last_air_time && d.last_contact_time && d.current_contact_time),
+                    "air/contact timers must be all set or all null");
+    }
+    for (int s = 0; s < d.num_ticks; ++s)
+        MDP_REQUIRE(d.tick_timestamp[s] && d.tick_timestamp_last_update[s] && d.tick_is_outdated[s], "tick sensor %d: null buffer", s);
+    auto blocks = [](int64_t work) { return (unsigned)((work + 255) / 256); };
+    plan->nb_root = has_root ? blocks((int64_t)N * 13) : 0;
+    plan->nb_joint = has_joint ? blocks((int64_t)N * d.num_joints) : 0;
+    if (has_contact) {
+        int epb = 256 / d.num_contact_bodies;
+        plan->nb_contact = (unsigned)(((int64_t)N + epb - 1) / epb);
+    }
+    plan->nb_tick = d.num_ticks ? blocks((int64_t)N * d.num_ticks) : 0;
+    plan->total = plan->nb_root + plan->nb_joint + plan->nb_contact + plan->nb_tick;
+    if (!has_joint) { plan->d.joint_acc = nullptr; plan->d.joint_pos = nullptr; plan->d.joint_vel = nullptr; }
+    return MDP_OK;
+}
+
+}  // namespace mdp

@@ -31,6 +31,7 @@ class ManagerBasedRLEnv:
         self.num_envs = cfg.scene.num_envs
         self.auto_reset = auto_reset
         self.fuse_post_physics = True   # episode counter + terminations + rewards in one launch
+        self.fuse_substeps = True       # scene.update(k) + write_data_to_sim(k+1) in one launch
         self.extras: dict[str, Any] = {}
         robot_cfg = cfg.scene.robot
         nj, nb = len(robot_cfg.joint_names), len(robot_cfg.body_names)
@@ -90,11 +91,22 @@ class ManagerBasedRLEnv:
     def step(self, action: torch.Tensor):
         """manager_based_rl_env.py:152-241"""
         self.action_manager.process_action(action.to(self.device))
-        for _ in range(self.cfg.decimation):
-            self.action_manager.apply_action()
-            self.scene.write_data_to_sim()
+        decimation = self.cfg.decimation
+        self.action_manager.apply_action()
+        self.scene.write_data_to_sim()
+        for k in range(decimation):
             self.physics.advance()                      # sim.step(render=False): synthetic / replayed
-            self.scene.update(dt=self.physics_dt)
+            if k + 1 < decimation:
+                # scene.update(k), apply_action(k+1), write_data_to_sim(k+1): nothing steps physics between them, so
+                # they share one launch when the actuator can carry the update (same values, same order of writes)
+                self.action_manager.apply_action()
+                if self.fuse_substeps:
+                    self.scene.update_and_write(self.physics_dt)
+                else:
+                    self.scene.update(dt=self.physics_dt)
+                    self.scene.write_data_to_sim()
+            else:
+                self.scene.update(dt=self.physics_dt)
         self.common_step_counter += 1
         if self.fuse_post_physics and self._can_fuse_post_physics():
             self._termination_reward_fused()

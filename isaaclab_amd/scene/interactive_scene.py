@@ -58,30 +58,53 @@ class InteractiveScene:
         for sensor in self.sensors.values():
             sensor.update(dt, force_recompute=not self.lazy_sensor_update)
 
-    def _update_fused(self, dt: float) -> bool:
-        import ctypes as C
-
+    def _scene_update_desc(self, dt: float):
+        """Descriptor of the fused post-physics launch, or None when some entity cannot describe its share."""
         from .. import _lib as L
 
         if len(self.articulations) != 1 or self.rigid_objects:
-            return False
+            return None
         art = next(iter(self.articulations.values()))
         if not hasattr(art.data, "fill_scene_update"):
-            return False
+            return None
         d = L.MdpSceneUpdate()
         force = not self.lazy_sensor_update
         seen_contact = False
         for sensor in self.sensors.values():
             if hasattr(sensor, "fill_scene_update") and not seen_contact:
                 if not sensor.fill_scene_update(d, force):
-                    return False
+                    return None
                 seen_contact = True
             elif hasattr(sensor, "fill_scene_tick"):
                 if not sensor.fill_scene_tick(d, force):
-                    return False
+                    return None
             else:
-                return False
+                return None
         art.data.fill_scene_update(d, dt)
+        return d, art
+
+    def _update_fused(self, dt: float) -> bool:
+        import ctypes as C
+
+        from .. import _lib as L
+
+        plan = self._scene_update_desc(dt)
+        if plan is None:
+            return False
+        d, art = plan
         L.check(L.lib.mdp_scene_update(C.byref(d), float(dt), L.stream(self.device)))
         art.data.commit_scene_update(dt)
         return True
+
+    def update_and_write(self, dt: float) -> None:
+        """``update(dt)`` immediately followed by ``write_data_to_sim()`` -- the tail of physics sub-step k and the head
+        of sub-step k+1 (manager_based_rl_env.py:184-195), which have no physics step between them.  When the single
+        actuator group can carry it, both run as ONE launch (``mdp_actuator_*_compute_after_update``)."""
+        plan = self._scene_update_desc(dt) if self.fused_update else None
+        if plan is None or not plan[1].can_carry_update:
+            self.update(dt)
+            self.write_data_to_sim()
+            return
+        d, art = plan
+        art.data.commit_scene_update(dt)      # the buffers are fresh once the launch below has run
+        art.write_data_to_sim(carry_update=(d, dt))

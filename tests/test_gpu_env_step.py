@@ -21,6 +21,7 @@ def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, **kw):
     if not fused:      # the per-entity / per-manager launches of the reference call structure
         env.scene.fused_update = False
         env.fuse_post_physics = False
+        env.fuse_substeps = False
     outs = []
     for t in range(steps):
         rec.feed(t)
