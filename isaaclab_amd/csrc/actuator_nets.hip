@@ -16,6 +16,7 @@
 #include "mdp_host.hpp"
 #include "scene_update_device.hpp"
 
+#include <cstdlib>
 #include <vector>
 
 using namespace mdp;
@@ -93,7 +94,25 @@ MDP_DEV float act_fn(float x, int a) {
         default: return x;
     }
 }
-MDP_DEV float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// LSTM gate non-linearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, 1 ulp each).  The gate math is
+// what bounds the LSTM kernels (20 sigmoid/tanh per lane and row group; libm expf / tanhf cost 15-40 VALU
+// instructions each, these 5-12), and the error stays two orders below the 1e-5 parity tolerance:
+//   sigmoid: relative error <= ~(|x| log2e + 2) * 2^-24  (1e-6 at |x| = 10);
+//   tanh, |x| >= 0.125: (1 - t) / (1 + t) with t = exp(-2|x|), cancellation bounded by 1 / (1 - e^-0.25) = 4.5;
+//   tanh, |x| <  0.125: odd Taylor polynomial to x^9 (truncation < 2e-11 relative).
+MDP_DEV float sigmoidf_(float x) {
+    float t = __builtin_amdgcn_exp2f(x * -1.44269504088896340736f);
+    return __builtin_amdgcn_rcpf(1.0f + t);
+}
+MDP_DEV float tanhf_(float x) {
+    float ax = fabsf(x);
+    float t = __builtin_amdgcn_exp2f(ax * -2.88539008177792681472f);
+    float big = (1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t);
+    float x2 = x * x;
+    float small = ax * (1.0f + x2 * (-0.33333333333f + x2 * (0.13333333333f + x2 * (-0.05396825397f + x2 * 0.02186948854f))));
+    float r = ax < 0.125f ? small : big;
+    return copysignf(r, x);
+}
 
 struct NetDev {
     mdp_net_desc_t d;
@@ -164,33 +183,69 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
        const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
        float* __restrict__ computed, float* __restrict__ applied) {
     constexpr int TPL = H / 4;
-    extern __shared__ float lds[];
+    extern __shared__ __align__(16) float lds[];
     if (blockIdx.x >= nb_act) {
         scene_update_block(upd, dt, blockIdx.x - nb_act, nb_root, nb_joint, nb_contact);
         return;
     }
-    for (int i = threadIdx.x; i < net.L.total; i += blockDim.x) lds[i] = packed[i];
-    __syncthreads();
     int lane = threadIdx.x & 63;
     int gq = lane >> 4, col = lane & 15;
     int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int64_t nwaves = (int64_t)nb_act * (blockDim.x >> 6);
     int64_t ngroups = (rows + 15) / 16;
-    for (int64_t g = wave; g < ngroups; g += nwaves) {
+    // Software pipeline: the global loads of a group (inputs and the (h, c) slices of every layer) are issued before
+    // the weights are staged / before the previous group's gates are evaluated, so the one dependent HBM round trip
+    // of the row overlaps the LDS staging instead of following it.  (The kernel is latency-bound: one group per wave
+    // at 4096 envs.)
+    constexpr int LMAX = 4;
+    float x0 = 0.0f, x1 = 0.0f;
+    float hreg[LMAX][TPL], creg[LMAX][TPL];
+    int64_t rr = 0;
+    bool valid = false;
+    auto load_group = [&](int64_t g) {
         int64_t row = g * 16 + col;
-        bool valid = row < rows;
-        int64_t rr = valid ? row : rows - 1;
+        valid = row < rows;
+        rr = valid ? row : rows - 1;
         int64_t e = rr / J;
         int j = (int)(rr - e * J);
         // actuator_net.py:80-81
-        float x0 = q_des[e * ld_q_des + j] - q[e * ld_q + j];
-        float x1 = qd[e * ld_qd + j];
-        float xin = gq == 0 ? x0 : (gq == 1 ? x1 : 0.0f);
+        x0 = q_des[e * ld_q_des + j] - q[e * ld_q + j];
+        x1 = qd[e * ld_qd + j];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+            if (l < net.d.lstm_layers) {
+                int64_t sbase = ((int64_t)l * rows + rr) * H + gq * TPL;
+#pragma unroll
+                for (int s = 0; s < TPL; ++s) { hreg[l][s] = hs[sbase + s]; creg[l][s] = cs[sbase + s]; }
+            }
+        }
+    };
+    int64_t g = wave;
+    if (g < ngroups) load_group(g);
+    {
+        // weights -> LDS, 128-bit copies (the blob is 256-byte aligned: every offset is a multiple of 64 floats)
+        const float4* src = reinterpret_cast<const float4*>(packed);
+        float4* dst = reinterpret_cast<float4*>(lds);
+        for (int i = threadIdx.x; i < net.L.total / 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    while (g < ngroups) {
+        const float cx0 = x0, cx1 = x1;
+        const bool cvalid = valid;
+        const int64_t crr = rr;
+        float hl_all[LMAX][TPL], cl_all[LMAX][TPL];
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l)
+#pragma unroll
+            for (int s = 0; s < TPL; ++s) { hl_all[l][s] = hreg[l][s]; cl_all[l][s] = creg[l][s]; }
+        int64_t gnext = g + nwaves;
+        if (gnext < ngroups) load_group(gnext);
+        float xin = gq == 0 ? cx0 : (gq == 1 ? cx1 : 0.0f);
         float prev[TPL];
 #pragma unroll
         for (int s = 0; s < TPL; ++s) prev[s] = 0.0f;
 #pragma unroll
-        for (int l = 0; l < 4; ++l) {
+        for (int l = 0; l < LMAX; ++l) {
             if (l < net.d.lstm_layers) {
                 f32x4 acc[TPL];
 #pragma unroll
@@ -207,25 +262,22 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
                         for (int t = 0; t < TPL; ++t) acc[t] = mfma4(w[(s * TPL + t) * 64 + lane], prev[s], acc[t]);
                 }
                 // recurrent part: this lane holds units gq*TPL .. gq*TPL+TPL-1 of row `col`
-                int64_t sbase = ((int64_t)l * rows + rr) * H + gq * TPL;
-                float hl[TPL], cl[TPL];
-#pragma unroll
-                for (int s = 0; s < TPL; ++s) { hl[s] = hs[sbase + s]; cl[s] = cs[sbase + s]; }
+                int64_t sbase = ((int64_t)l * rows + crr) * H + gq * TPL;
 #pragma unroll
                 for (int s = 0; s < TPL; ++s)
 #pragma unroll
                     for (int t = 0; t < TPL; ++t)
-                        acc[t] = mfma4(w[((ks_in + s) * TPL + t) * 64 + lane], hl[s], acc[t]);
+                        acc[t] = mfma4(w[((ks_in + s) * TPL + t) * 64 + lane], hl_all[l][s], acc[t]);
 #pragma unroll
                 for (int t = 0; t < TPL; ++t) {
                     float ig = sigmoidf_(acc[t][0]);
                     float fg = sigmoidf_(acc[t][1]);
-                    float gg = tanhf(acc[t][2]);
+                    float gg = tanhf_(acc[t][2]);
                     float og = sigmoidf_(acc[t][3]);
-                    float cn = fg * cl[t] + ig * gg;
-                    float hn = og * tanhf(cn);
+                    float cn = fg * cl_all[l][t] + ig * gg;
+                    float hn = og * tanhf_(cn);
                     prev[t] = hn;
-                    if (valid) { hs[sbase + t] = hn; cs[sbase + t] = cn; }
+                    if (cvalid) { hs[sbase + t] = hn; cs[sbase + t] = cn; }
                 }
             }
         }
@@ -233,7 +285,129 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
 #pragma unroll
         for (int s = 0; s < 8; ++s) in_first[s] = s < TPL ? prev[s < TPL ? s : 0] : 0.0f;
         float tau = run_mlp(net, lds, lane, in_first);
-        if (valid && gq == 0) dc_clip_store(tau, x1, row, eff_lim, vel_lim, sat, computed, applied);
+        if (cvalid && gq == 0) dc_clip_store(tau, cx1, crr, eff_lim, vel_lim, sat, computed, applied);
+        g = gnext;
+    }
+}
+
+// The ANYdrive shape (hidden 8, <= 2 layers, Linear(8 -> 1) decoder): every weight fragment a lane needs fits in ~40
+// registers, so they are loaded straight from global memory (L2-resident, coalesced 256-B rows) together with the
+// row's inputs -- ONE round trip, no LDS staging, no block barrier, no LDS read in front of each MFMA.  The generic
+// kernel above spends 63 % of its wave cycles parked on s_waitcnt (SQ_WAIT_ANY) for exactly those.  Same MFMA / gate
+// order as k_lstm: bit-identical outputs.
+template <int NL>
+__global__ void __launch_bounds__(256)
+k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
+            NetDev net, const float* __restrict__ packed, int64_t rows, int J,
+            const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
+            const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
+            const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
+            float* __restrict__ computed, float* __restrict__ applied) {
+    constexpr int H = 8, TPL = 2;
+    if (blockIdx.x >= nb_act) {
+        scene_update_block(upd, dt, blockIdx.x - nb_act, nb_root, nb_joint, nb_contact);
+        return;
+    }
+    int lane = threadIdx.x & 63;
+    int gq = lane >> 4, col = lane & 15;
+    int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t nwaves = (int64_t)nb_act * (blockDim.x >> 6);
+    int64_t ngroups = (rows + 15) / 16;
+    float x0 = 0.0f, x1 = 0.0f;
+    float hreg[NL][TPL], creg[NL][TPL];
+    int64_t rr = 0;
+    bool valid = false;
+    auto load_group = [&](int64_t g) {
+        int64_t row = g * 16 + col;
+        valid = row < rows;
+        rr = valid ? row : rows - 1;
+        int64_t e = rr / J;
+        int j = (int)(rr - e * J);
+        x0 = q_des[e * ld_q_des + j] - q[e * ld_q + j];  // actuator_net.py:80-81
+        x1 = qd[e * ld_qd + j];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            int64_t sbase = ((int64_t)l * rows + rr) * H + gq * TPL;
+#pragma unroll
+            for (int s = 0; s < TPL; ++s) { hreg[l][s] = hs[sbase + s]; creg[l][s] = cs[sbase + s]; }
+        }
+    };
+    int64_t g = wave;
+    if (g < ngroups) load_group(g);
+    // weight / bias fragments of this lane (layer 0 has one input k-step, deeper layers TPL)
+    float w[NL][2 * TPL * TPL], bias[NL][4 * TPL], wm[TPL], bm[4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const float* pw = packed + net.L.lstm_w[l];
+        const int nk = (l == 0 ? 1 : TPL) + TPL;
+#pragma unroll
+        for (int k = 0; k < 2 * TPL; ++k)
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) w[l][k * TPL + t] = k < nk ? pw[(k * TPL + t) * 64 + lane] : 0.0f;
+        const float* pb = packed + net.L.lstm_b[l];
+#pragma unroll
+        for (int i = 0; i < 4 * TPL; ++i) bias[l][i] = pb[i * 64 + lane];
+    }
+#pragma unroll
+    for (int s = 0; s < TPL; ++s) wm[s] = packed[net.L.mlp_w[0] + (s * MLP_NT) * 64 + lane];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bm[r] = packed[net.L.mlp_b[0] + r * 64 + lane];
+    const int act = net.d.mlp_act[0];
+    while (g < ngroups) {
+        const float cx0 = x0, cx1 = x1;
+        const bool cvalid = valid;
+        const int64_t crr = rr;
+        float hl[NL][TPL], cl[NL][TPL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+#pragma unroll
+            for (int s = 0; s < TPL; ++s) { hl[l][s] = hreg[l][s]; cl[l][s] = creg[l][s]; }
+        int64_t gnext = g + nwaves;
+        if (gnext < ngroups) load_group(gnext);
+        float xin = gq == 0 ? cx0 : (gq == 1 ? cx1 : 0.0f);
+        float prev[TPL] = {0.0f, 0.0f};
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            f32x4 acc[TPL];
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) {
+                acc[t][0] = bias[l][t * 4 + 0]; acc[t][1] = bias[l][t * 4 + 1];
+                acc[t][2] = bias[l][t * 4 + 2]; acc[t][3] = bias[l][t * 4 + 3];
+            }
+            const int ks_in = l == 0 ? 1 : TPL;
+            if (l == 0) {
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) acc[t] = mfma4(w[l][t], xin, acc[t]);
+            } else {
+#pragma unroll
+                for (int s = 0; s < TPL; ++s)
+#pragma unroll
+                    for (int t = 0; t < TPL; ++t) acc[t] = mfma4(w[l][s * TPL + t], prev[s], acc[t]);
+            }
+#pragma unroll
+            for (int s = 0; s < TPL; ++s)
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) acc[t] = mfma4(w[l][(ks_in + s) * TPL + t], hl[l][s], acc[t]);
+            int64_t sbase = ((int64_t)l * rows + crr) * H + gq * TPL;
+#pragma unroll
+            for (int t = 0; t < TPL; ++t) {
+                float ig = sigmoidf_(acc[t][0]);
+                float fg = sigmoidf_(acc[t][1]);
+                float gg = tanhf_(acc[t][2]);
+                float og = sigmoidf_(acc[t][3]);
+                float cn = fg * cl[l][t] + ig * gg;
+                float hn = og * tanhf_(cn);
+                prev[t] = hn;
+                if (cvalid) { hs[sbase + t] = hn; cs[sbase + t] = cn; }
+            }
+        }
+        f32x4 acc;
+        acc[0] = bm[0]; acc[1] = bm[1]; acc[2] = bm[2]; acc[3] = bm[3];
+#pragma unroll
+        for (int s = 0; s < TPL; ++s) acc = mfma4(wm[s], prev[s], acc);
+        float tau = act_fn(acc[0], act);
+        if (cvalid && gq == 0) dc_clip_store(tau, cx1, crr, eff_lim, vel_lim, sat, computed, applied);
+        g = gnext;
     }
 }
 
@@ -419,6 +593,7 @@ extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* 
     make_layout(*desc, net.L);
     size_t lds_bytes = (size_t)net.L.total * sizeof(float);
     MDP_REQUIRE(lds_bytes <= 150 * 1024, "network too large for LDS staging (%zu bytes)", lds_bytes);
+    MDP_REQUIRE(((uintptr_t)packed_weights & 15) == 0, "packed_weights must be 16-byte aligned");
     unsigned nb_act = net_grid(rows);
     dim3 grid(nb_act + plan.total), block(256);
     hipStream_t s = as_stream(stream);
@@ -432,6 +607,22 @@ extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* 
                            ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,      \
                            saturation_effort, computed_effort, applied_effort);                                    \
     } while (0)
+    // register-resident weights for the ANYdrive shape (MDP_LSTM_GENERIC=1 forces the LDS kernel: parity tests)
+    static const bool force_generic = [] { const char* e = std::getenv("MDP_LSTM_GENERIC"); return e && e[0] == '1'; }();
+    if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1) {
+        if (desc->lstm_layers == 1)
+            hipLaunchKernelGGL(k_lstm8_reg<1>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
+                               plan.nb_contact, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                               joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
+                               saturation_effort, computed_effort, applied_effort);
+        else
+            hipLaunchKernelGGL(k_lstm8_reg<2>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
+                               plan.nb_contact, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                               joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
+                               saturation_effort, computed_effort, applied_effort);
+        MDP_LAUNCH_CHECK();
+        return MDP_OK;
+    }
     switch (desc->lstm_hidden) {
         case 8: LAUNCH(8); break;
         case 16: LAUNCH(16); break;

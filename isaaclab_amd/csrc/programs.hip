@@ -13,6 +13,7 @@
 #include "mesh_handle.hpp"
 #include "term_ops.h"
 
+#include <cstdlib>
 #include <vector>
 
 using namespace mdp;
@@ -41,7 +42,10 @@ struct mdp_program {
 static unsigned obs_grid(int num_envs, int O) {
     if (O <= 0 || num_envs <= 0) return 1;
     int epb = O >= 256 ? 1 : 256 / O;
-    return grid_for(((int64_t)num_envs + epb - 1) / epb, 1, 1 << 20);
+    // a block stages the term table once and then walks its envs: cap the grid so the staging (one dependent global
+    // round trip + barrier) is amortised over several envs instead of being paid by every env
+    static const int64_t cap = [] { const char* e = std::getenv("MDP_OBS_GRID"); return e ? (int64_t)std::atoi(e) : (int64_t)2048; }();
+    return grid_for(((int64_t)num_envs + epb - 1) / epb, 1, cap > 0 ? cap : 1 << 20);
 }
 
 namespace {
