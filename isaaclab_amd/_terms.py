@@ -51,6 +51,7 @@ class TermSpec:
     idx2: list[int] | None = None
     raycaster: Any = None           # sensor object for MDP_OBS_HEIGHT_SCAN_CAST
     before: list = field(default_factory=list)  # callables run before each launch (e.g. sensor lazy update)
+    lazy_sensors: list = field(default_factory=list)  # lazily evaluated sensors the `before` hooks refresh
     out_dtype: torch.dtype = torch.float32
 
     def to_struct(self, pool: list[int]) -> L.MdpTerm:

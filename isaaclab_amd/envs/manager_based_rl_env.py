@@ -32,6 +32,12 @@ class ManagerBasedRLEnv:
         self.auto_reset = auto_reset
         self.fuse_post_physics = True   # episode counter + terminations + rewards in one launch
         self.fuse_substeps = True       # scene.update(k) + write_data_to_sim(k+1) in one launch
+        # (terminations + rewards, command) and the height-scan cast on two streams (only without a reset in between)
+        self.concurrent_post_physics = torch.device(device).type == "cuda"
+        if self.concurrent_post_physics:
+            self._side_stream = torch.cuda.Stream(device=device)
+            self._ev_scene = torch.cuda.Event()
+            self._ev_side = torch.cuda.Event()
         self.extras: dict[str, Any] = {}
         robot_cfg = cfg.scene.robot
         nj, nb = len(robot_cfg.joint_names), len(robot_cfg.body_names)
@@ -108,19 +114,39 @@ class ManagerBasedRLEnv:
             else:
                 self.scene.update(dt=self.physics_dt)
         self.common_step_counter += 1
-        if self.fuse_post_physics and self._can_fuse_post_physics():
-            self._termination_reward_fused()
+        concurrent = (self.concurrent_post_physics and not self.auto_reset and self._can_fuse_post_physics()
+                      and not self._post_physics_reads_lazy_sensor())
+        if concurrent:
+            # Without the reset path between them (manager_based_rl_env.py:214-229) the chain terminations -> rewards ->
+            # command update and the height-scan cast only depend on the scene update above, not on each other: they
+            # go to two streams (two branches of a captured hipGraph) and join before the observations.
+            main = torch.cuda.current_stream(self.device)
+            side = self._side_stream
+            self._ev_scene.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(self._ev_scene)
+                self._termination_reward_fused()
+                self.command_manager.compute(dt=self.step_dt)   # after the rewards: they read the previous command
+                self._ev_side.record(side)
+            for sensor in self.scene.sensors.values():      # lazily evaluated sensors the observations will read
+                if hasattr(sensor, "fill_scene_tick"):
+                    sensor._update_outdated_buffers()
+            main.wait_event(self._ev_side)
         else:
-            self.episode_length_buf += 1
-            self.reset_buf = self.termination_manager.compute()
-            self.reward_buf = self.reward_manager.compute(dt=self.step_dt)
+            if self.fuse_post_physics and self._can_fuse_post_physics():
+                self._termination_reward_fused()
+            else:
+                self.episode_length_buf += 1
+                self.reset_buf = self.termination_manager.compute()
+                self.reward_buf = self.reward_manager.compute(dt=self.step_dt)
         self.reset_terminated = self.termination_manager.terminated
         self.reset_time_outs = self.termination_manager.time_outs
-        if self.auto_reset:
-            reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
-            if len(reset_env_ids) > 0:
-                self._reset_idx(reset_env_ids)
-        self.command_manager.compute(dt=self.step_dt)
+        if not concurrent:
+            if self.auto_reset:
+                reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+                if len(reset_env_ids) > 0:
+                    self._reset_idx(reset_env_ids)
+            self.command_manager.compute(dt=self.step_dt)
         self.obs_buf = self.observation_manager.compute()
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
@@ -130,6 +156,14 @@ class ManagerBasedRLEnv:
         if tm._program is None or rm._program is None:
             return False            # first step: the unfused calls build the programs (and discover user terms)
         return (len(tm.active_terms) > 0 and len(rm.active_terms) > 0 and not tm._external and not rm._external)
+
+    def _post_physics_reads_lazy_sensor(self) -> bool:
+        """True when a termination / reward term reads a lazily evaluated sensor (e.g. ``base_height_l2`` with a ray
+        caster): its cast is then ordered before that term and cannot overlap it."""
+        for prog in (self.termination_manager._program, self.reward_manager._program):
+            if prog is not None and any(getattr(spec, "lazy_sensors", None) for spec in prog.specs):
+                return True
+        return False
 
     def _termination_reward_fused(self):
         """manager_based_rl_env.py:199-206: ``episode_length_buf += 1``, ``termination_manager.compute()`` and

@@ -71,12 +71,14 @@ def base_height_l2(env, target_height: float, asset_cfg: SceneEntityCfg = SceneE
     st, ld, before = root_state(env.scene[asset_cfg.name])
     p = {0: st}
     i = {0: ld}
+    lazy = []
     if sensor_cfg is not None:
         sensor = env.scene[sensor_cfg.name]
         p[1] = sensor._data.ray_hits_w
         i[1] = sensor.num_rays
         before = before + [lambda s=sensor: s.data]
-    return TermSpec(REWARD, "MDP_REW_BASE_HEIGHT_L2", p=p, i=i, f={0: target_height}, before=before)
+        lazy = [sensor]
+    return TermSpec(REWARD, "MDP_REW_BASE_HEIGHT_L2", p=p, i=i, f={0: target_height}, before=before, lazy_sensors=lazy)
 
 
 @lowered(REWARD)

@@ -22,6 +22,7 @@ def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, **kw):
         env.scene.fused_update = False
         env.fuse_post_physics = False
         env.fuse_substeps = False
+        env.concurrent_post_physics = False
     outs = []
     for t in range(steps):
         rec.feed(t)
