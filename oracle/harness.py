@@ -6,7 +6,7 @@ import numpy as np
 
 from . import mdp_np as P
 from .actuators_np import F
-from .velocity_step import VelocityStepOracle, anymal_spec
+from .velocity_step import VelocityStepOracle, anymal_spec, h1_spec
 
 
 def net_weights_from_module(network):
@@ -38,6 +38,8 @@ def build_oracle(rec, threads: int = 0) -> VelocityStepOracle:
     if rec.name.startswith("anymal"):
         spec = anymal_spec(rec.num_envs, rec.env_origins, rough=rough, caster=caster, ray_starts=starts, ray_dirs=dirs,
                            actuator=actuator, flat_weights=rec.name == "anymal_d_flat", threads=threads)
+    elif rec.name == "h1_rough":
+        spec = h1_spec(rec.num_envs, rec.env_origins, caster, starts, dirs, threads=threads)
     else:
         raise NotImplementedError(f"no oracle spec for config '{rec.name}'")
     orc = VelocityStepOracle(spec)
@@ -47,9 +49,12 @@ def build_oracle(rec, threads: int = 0) -> VelocityStepOracle:
 
 def frame_dict(rec, t: int) -> dict:
     n = rec.num_envs
-    return dict(root_state=P.state_pack(rec.field("root_transforms", t), rec.field("root_velocities", t)),
-                joint_pos=rec.field("dof_positions", t), joint_vel=rec.field("dof_velocities", t),
-                forces=rec.field("net_contact_forces", t).reshape(n, -1, 3))
+    d = dict(root_state=P.state_pack(rec.field("root_transforms", t), rec.field("root_velocities", t)),
+             joint_pos=rec.field("dof_positions", t), joint_vel=rec.field("dof_velocities", t),
+             forces=rec.field("net_contact_forces", t).reshape(n, -1, 3))
+    if "link_transforms" in rec.fields:
+        d["body_state"] = P.state_pack(rec.field("link_transforms", t), rec.field("link_velocities", t))
+    return d
 
 
 def oracle_step(orc: VelocityStepOracle, rec, k: int):

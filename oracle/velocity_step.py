@@ -61,6 +61,7 @@ class VelocityStepOracle:
             self.rc_ts = np.zeros(n, np.float32)
             self.rc_last = np.zeros(n, np.float32)
             self.rc_outdated = np.ones(n, bool)
+        self._body_state = None
         act = s["actuator"]
         if act["kind"] == "lstm":
             L, H = len(act["lstm_weights"]), act["lstm_weights"][0][1].shape[1]
@@ -82,6 +83,8 @@ class VelocityStepOracle:
         if self.s.get("height_scan") is not None:
             E["ray_hits_w"] = self.ray_hits
             E["sensor_pos_w"] = self.sensor_pos
+        if self._body_state is not None:
+            E["body_state"] = self._body_state
         return E
 
     def _actuator(self, q, qd):
@@ -133,6 +136,7 @@ class VelocityStepOracle:
                 self.rc_outdated |= (self.rc_ts - self.rc_last + F(1e-6)) >= F(s["height_scan"]["update_period"])
         fr = substep_frames[-1]
         root = fr["root_state"]
+        self._body_state = fr.get("body_state")
         self.episode_length += 1
         E = self.env_dict(root, fr["joint_pos"], fr["joint_vel"])
         # terminations
@@ -216,6 +220,85 @@ def anymal_spec(num_envs, env_origins, rough=True, caster=None, ray_starts=None,
         env_origins=np.asarray(env_origins, np.float32), action_scale=0.5,
         contact=dict(history=3, period=0.005, threshold=1.0), height_scan=height,
         command=dict(resampling_time_range=(10.0, 10.0), lin_vel_x=(-1.0, 1.0), lin_vel_y=(-1.0, 1.0),
+                     ang_vel_z=(-1.0, 1.0), heading=(-math.pi, math.pi), heading_command=True,
+                     rel_heading_envs=1.0, rel_standing_envs=0.02, heading_control_stiffness=0.5),
+    )
+
+
+def _match(names, patterns):
+    import re
+
+    pats = [patterns] if isinstance(patterns, str) else list(patterns)
+    return [i for i, n in enumerate(names) if any(re.fullmatch(p, n) for p in pats)]
+
+
+def h1_spec(num_envs, env_origins, caster, ray_starts, ray_dirs, threads=0):
+    """Term tables of Isaac-Velocity-Rough-H1-v0 (config/h1/rough_env_cfg.py:19-115 over velocity_env_cfg.py:116-265;
+    robot constants ASSETS/robots/unitree.py:216-260: 19 joints, three implicit-actuator groups)."""
+    joint_names = ["left_hip_yaw", "right_hip_yaw", "torso", "left_hip_roll", "right_hip_roll", "left_shoulder_pitch",
+                   "right_shoulder_pitch", "left_hip_pitch", "right_hip_pitch", "left_shoulder_roll",
+                   "right_shoulder_roll", "left_knee", "right_knee", "left_shoulder_yaw", "right_shoulder_yaw",
+                   "left_ankle", "right_ankle", "left_elbow", "right_elbow"]
+    body_names = ["pelvis"] + [n + "_link" for n in joint_names]
+    j = len(joint_names)
+
+    def per_joint(table, default=0.0):
+        out = np.full(j, default, np.float32)
+        for pat, val in table.items():
+            out[_match(joint_names, pat)] = val
+        return out
+
+    dq = per_joint({".*_hip_yaw": 0.0, ".*_hip_roll": 0.0, ".*_hip_pitch": -0.28, ".*_knee": 0.79, ".*_ankle": -0.52,
+                    "torso": 0.0, ".*_shoulder_pitch": 0.28, ".*_shoulder_roll": 0.0, ".*_shoulder_yaw": 0.0,
+                    ".*_elbow": 0.52})
+    kp = per_joint({".*_hip_yaw": 150.0, ".*_hip_roll": 150.0, ".*_hip_pitch": 200.0, ".*_knee": 200.0, "torso": 200.0,
+                    ".*_ankle": 20.0, ".*_shoulder_.*": 40.0, ".*_elbow": 40.0})
+    kd = per_joint({".*_hip_.*": 5.0, ".*_knee": 5.0, "torso": 5.0, ".*_ankle": 4.0, ".*_shoulder_.*": 10.0,
+                    ".*_elbow": 10.0})
+    lim = per_joint({".*": 300.0})
+    lim[_match(joint_names, ".*_ankle")] = 100.0
+    feet = _match(body_names, ".*ankle_link")
+    torso = _match(body_names, ".*torso_link")
+    ankles = _match(joint_names, ".*_ankle")
+    hips = _match(joint_names, [".*_hip_yaw", ".*_hip_roll"])
+    arms = _match(joint_names, [".*_shoulder_.*", ".*_elbow"])
+    torso_j = _match(joint_names, "torso")
+    std = math.sqrt(0.25)
+    rewards = [
+        ("track_lin_vel_xy_exp", lambda E: T.track_lin_vel_xy_yaw_frame_exp(E, 0.5), 1.0),
+        ("track_ang_vel_z_exp", lambda E: T.track_ang_vel_z_world_exp(E, 0.5), 1.0),
+        ("ang_vel_xy_l2", T.ang_vel_xy_l2, -0.05),
+        ("dof_torques_l2", T.joint_torques_l2, 0.0),
+        ("dof_acc_l2", T.joint_acc_l2, -1.25e-7),
+        ("action_rate_l2", T.action_rate_l2, -0.005),
+        ("feet_air_time", lambda E: T.feet_air_time_positive_biped(E, 0.4, feet), 0.25),
+        ("flat_orientation_l2", T.flat_orientation_l2, -1.0),
+        ("dof_pos_limits", lambda E: T.joint_pos_limits(E, ankles), -1.0),
+        ("termination_penalty", T.is_terminated, -200.0),
+        ("feet_slide", lambda E: T.feet_slide(E, feet, feet), -0.25),
+        ("joint_deviation_hip", lambda E: T.joint_deviation_l1(E, hips), -0.2),
+        ("joint_deviation_arms", lambda E: T.joint_deviation_l1(E, arms), -0.2),
+        ("joint_deviation_torso", lambda E: T.joint_deviation_l1(E, torso_j), -0.1),
+    ]
+    del std
+    terminations = [("time_out", T.time_out, True), ("base_contact", lambda E: T.illegal_contact(E, 1.0, torso), False)]
+    obs_terms = [
+        ("base_lin_vel", T.base_lin_vel, (-0.1, 0.1), None), ("base_ang_vel", T.base_ang_vel, (-0.2, 0.2), None),
+        ("projected_gravity", T.projected_gravity, (-0.05, 0.05), None),
+        ("velocity_commands", T.generated_commands, None, None),
+        ("joint_pos", T.joint_pos_rel, (-0.01, 0.01), None), ("joint_vel", T.joint_vel_rel, (-1.5, 1.5), None),
+        ("actions", T.last_action, None, None),
+        ("height_scan", T.height_scan, (-0.1, 0.1), (-1.0, 1.0)),
+    ]
+    return dict(
+        num_envs=num_envs, joint_names=joint_names, body_names=body_names, default_joint_pos=dq,
+        soft_limit_factor=0.9, joint_pos_limits=(-2.6, 2.6),
+        actuator=dict(kind="implicit", kp=kp, kd=kd, effort_limit=lim, velocity_limit=F(100.0)),
+        rewards=rewards, terminations=terminations, obs_terms=obs_terms, sim_dt=0.005, decimation=4,
+        episode_length_s=20.0, env_origins=np.asarray(env_origins, np.float32), action_scale=0.5,
+        contact=dict(history=3, period=0.005, threshold=1.0),
+        height_scan=dict(starts=ray_starts, dirs=ray_dirs, caster=caster, update_period=0.02, threads=threads),
+        command=dict(resampling_time_range=(10.0, 10.0), lin_vel_x=(0.0, 1.0), lin_vel_y=(0.0, 0.0),
                      ang_vel_z=(-1.0, 1.0), heading=(-math.pi, math.pi), heading_command=True,
                      rel_heading_envs=1.0, rel_standing_envs=0.02, heading_control_stiffness=0.5),
     )

@@ -101,3 +101,17 @@ def test_anymal_c_rough_lstm(device):
     compare(outs, ref)
     act = env.scene["robot"].actuators["legs"]
     assert act.sea_hidden_state.abs().max().item() > 0.0
+
+
+@pytest.mark.parametrize("n,fused", ((48, True), (19, False)))
+def test_h1_rough(device, n, fused):
+    """BASELINE config C4 shape (Isaac-Velocity-Rough-H1-v0: 19 joints in three implicit-actuator groups addressed by
+    index lists, 20 bodies, biped reward terms incl. feet_slide on body velocities, 256-dim observation)."""
+    from oracle.harness import build_oracle, replay_oracle
+
+    env, rec, outs = run_env("h1_rough", n, 5, device, seed=15, small_terrain=True, fused=fused)
+    assert outs[0][0].shape == (n, 256)
+    orc = build_oracle(rec)
+    assert env.reward_manager.active_terms == [name for name, _, _ in orc.s["rewards"]]
+    assert len(env.scene["robot"].actuators) == 3
+    compare(outs, replay_oracle(rec, 5))

@@ -250,3 +250,33 @@ def test_manager_errors_and_user_terms(golden, device):
         om.compute_group("nope")
     assert isinstance(str(om), str) and "policy" in str(om)
     assert torch.is_tensor(rm._reward_buf)
+
+
+def test_observation_noise_from_device_generator(golden, device):
+    """UniformNoise / GaussianNoise drawn by the fused kernel (noise_model.py:45-69 laws; torch's stream cannot be
+    reproduced): range, moments, no reuse of a draw across columns, envs or launches."""
+    import isaaclab_amd.envs.mdp as mdp
+    import isaaclab_amd.managers as mg
+    from isaaclab_amd.utils.noise import GaussianNoiseCfg, UniformNoiseCfg
+
+    G = golden("terms")
+    env, t = make_device_env(G, "n64_", device)
+    grp = mg.ObservationGroupCfg()
+    grp.enable_corruption = True
+    grp.concatenate_terms = True
+    grp.joint_pos = mg.ObservationTermCfg(func=mdp.joint_pos, noise=UniformNoiseCfg(n_min=-0.2, n_max=0.6))
+    grp.joint_vel = mg.ObservationTermCfg(func=mdp.joint_vel, noise=GaussianNoiseCfg(mean=0.25, std=1.5))
+    grp.clean = mg.ObservationTermCfg(func=mdp.last_action)
+    om = mg.ObservationManager({"policy": grp}, env, seed=123)
+    clean = np.concatenate([G["n64_in_joint_pos"], G["n64_in_joint_vel"], G["n64_in_action"]], axis=1)
+    draws = np.stack([to_np(om.compute()["policy"]) - clean for _ in range(40)])   # (40, 64, 36)
+    u, g, z = draws[..., :12], draws[..., 12:24], draws[..., 24:]
+    assert np.abs(z).max() < 1e-6
+    assert u.min() >= -0.2 - 1e-6 and u.max() <= 0.6 + 1e-6
+    assert abs(u.mean() - 0.2) < 0.01 and abs(u.std() - 0.8 / np.sqrt(12)) < 0.01
+    assert abs(g.mean() - 0.25) < 0.03 and abs(g.std() - 1.5) < 0.03
+    # every draw is its own: (almost) no repeated value across columns / envs / launches
+    assert len(np.unique(np.round(u.ravel(), 7))) > 0.98 * u.size
+    assert abs(np.corrcoef(u[:, :, 0].ravel(), u[:, :, 1].ravel())[0, 1]) < 0.08
+    assert abs(np.corrcoef(u[:-1].ravel(), u[1:].ravel())[0, 1]) < 0.03
+    assert abs(np.corrcoef(u.ravel(), g.ravel())[0, 1]) < 0.03
