@@ -1,0 +1,86 @@
+"""GPU at BASELINE.json's full per-GPU sizes.  The oracle cannot replay 4096+ envs x several steps in seconds, but every
+row of the path is independent per env, so (a) the oracle replays a SLICE of the envs of the full-size run on the very
+same frames -- any cross-env interference, indexing or launch-geometry bug at full size breaks the slice -- and (b)
+size-independent properties are checked on all envs: dones = terminated | time_outs, vertical rays keep their xy, hits
+lie on or below the ray start, repeated casts are idempotent, episode sums equal the accumulated rewards."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, to_np
+
+pytestmark = pytest.mark.gpu
+
+
+def slice_recording(rec, ids):
+    """Recording restricted to env ids (frames are field-major (N, w) blocks)."""
+    import copy
+
+    import torch
+
+    sub = copy.copy(rec)
+    n = rec.num_envs
+    sub.num_envs = len(ids)
+    fields, chunks, off = {}, [], 0
+    idt = torch.as_tensor(ids)
+    for name, (o, s, shape) in rec.fields.items():
+        per_env = s // n if n else 0
+        block = rec.frames[:, o : o + s].reshape(rec.frames.shape[0], n, per_env)[:, idt]
+        size = len(ids) * per_env
+        new_shape = (len(ids) * (shape[0] // n),) + tuple(shape[1:]) if shape[0] != n else (len(ids),) + tuple(shape[1:])
+        fields[name] = (off, size, new_shape)
+        pad = (-size) % 4
+        chunks.append(block.reshape(rec.frames.shape[0], size))
+        if pad:
+            chunks.append(torch.zeros(rec.frames.shape[0], pad))
+        off += size + pad
+    sub.frames = torch.cat(chunks, dim=1)
+    sub.fields = fields
+    sub.actions = rec.actions[:, idt]
+    sub.env_origins = rec.env_origins[np.asarray(ids)]
+    if rec.cmd_uniforms is not None:
+        sub.cmd_uniforms = rec.cmd_uniforms[:, idt]
+    sub.obs_noise = {k: v[:, idt] for k, v in rec.obs_noise.items()}
+    return sub
+
+
+@pytest.mark.parametrize("name,n", (("anymal_d_rough", 4096), ("anymal_c_rough", 16384)))
+def test_full_size_slice_vs_oracle_and_properties(device, name, n):
+    """configs[1] (Rough Anymal-D, 4096 envs, 765,952 rays per cast) and configs[2] (Anymal-C LSTM, 16384 envs)."""
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+    from oracle.harness import replay_oracle
+
+    steps = 3
+    env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=21, small_terrain=True)
+    outs, rewards = [], torch.zeros(n, device=device)
+    for t in range(steps):
+        rec.feed(t)
+        obs, rew, term, trunc, _ = env.step(rec.actions[t].to(device))
+        rewards += rew
+        outs.append((to_np(obs["policy"]), to_np(rew), to_np(term), to_np(trunc)))
+        np.testing.assert_array_equal(to_np(env.reset_buf), outs[-1][2] | outs[-1][3])
+    # (a) a strided slice + the last envs, replayed by the oracle
+    ids = sorted(set(range(0, n, n // 96)) | set(range(n - 17, n)))
+    ref = replay_oracle(slice_recording(rec, ids), steps)
+    for t in range(steps):
+        got = [a[ids] for a in outs[t]]
+        np.testing.assert_array_equal(got[2], ref[t][2])
+        np.testing.assert_array_equal(got[3], ref[t][3])
+        assert_close(got[1], ref[t][1], rtol=1e-5, atol=2e-6, msg=f"reward step {t}")
+        assert_close(got[0], ref[t][0], rtol=1e-5, atol=1e-5, msg=f"obs step {t}")
+    # (b) properties over all envs
+    rm = env.reward_manager
+    total = torch.stack([rm._episode_sums[k] for k in rm.active_terms]).sum(0)
+    assert_close(to_np(total), to_np(rewards), rtol=1e-4, atol=1e-5)
+    hs = env.scene["height_scanner"]
+    hits = to_np(hs.data.ray_hits_w)
+    assert hits.shape == (n, 187, 3) and np.isfinite(hits).all()
+    pos = to_np(hs.data.pos_w)
+    assert np.all(hits[..., 2] <= pos[:, None, 2] + 20.0 + 1e-4)            # below the ray start (offset 20 m)
+    yaw_free = np.linalg.norm(hits[..., :2] - pos[:, None, :2], axis=-1)   # pattern is 1.6 x 1.0 m around the sensor
+    assert yaw_free.max() <= np.hypot(0.8, 0.5) + 1e-4
+    first = hits.copy()
+    hs._is_outdated.fill_(True)
+    np.testing.assert_array_equal(to_np(hs.data.ray_hits_w), first)        # idempotent re-cast
+    assert np.isfinite(outs[-1][0]).all() and np.abs(outs[-1][0][:, -187:]).max() <= 1.0   # height scan clipped to [-1, 1]
