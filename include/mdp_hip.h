@@ -275,13 +275,14 @@ int mdp_raycast(const mdp_mesh_t* mesh, int64_t num_rays,
  * pattern_vertical_down != 0 is the caller's promise that every local direction is (0, 0, -c), c > 0 (the height-scan
  * grid pattern, patterns.py:42-56): with yaw-only attachment the rays are then vertical in the world and a
  * specialised kernel (same arithmetic, half the registers, one grid cell per ray) is used. */
+struct mdp_height_scan_obs;
 int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int num_rays,
                          const float* root_pose, int ld_pose, const float* drift,
                          const float* ray_starts_local, const float* ray_dirs_local,
                          int attach_yaw_only, int pattern_vertical_down, float max_dist,
                          float* pos_w, float* quat_w, float* ray_hits_w,
                          const float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
-                         void* stream);
+                         const struct mdp_height_scan_obs* scan, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Manager term programs (LAB/managers/{observation,reward,termination}_manager.py,
@@ -321,6 +322,22 @@ typedef struct {
     /* reward: weight (reward_manager.py:148) ; termination: time_out flag in i3 */
     float weight;
 } mdp_term_t;
+
+/* height_scan observation (LAB/envs/mdp/observations.py:165-173: sensor.pos_w.z - ray_hits_w.z - offset) and its
+ * post-processing (observation_manager.py:313-318: noise -> clip -> scale, described by the post-processing fields of
+ * `post`) written by the CAST kernel itself into columns [col_offset, col_offset + R) of the observation tensor: the
+ * optional last argument of mdp_raycaster_update.  Envs that are not outdated get their columns from the stored hits.
+ * rng: device uint64 {seed, one epoch counter per launch block ...} (1 + num_envs words), advanced by the kernel; only
+ * read when `post` asks for generated noise.  The observation program marks these columns MDP_OBS_SKIP. */
+typedef struct mdp_height_scan_obs {
+    float* obs;
+    int32_t ld_obs;
+    int32_t col_offset;
+    float offset;
+    int32_t pad0;
+    uint64_t* rng;
+    mdp_term_t post;
+} mdp_height_scan_obs_t;
 
 /* Ray-caster binding for a fused height-scan observation term (op MDP_OBS_HEIGHT_SCAN_CAST): the
  * term's p4 holds a HOST pointer to this struct at mdp_program_create time; the builder copies it

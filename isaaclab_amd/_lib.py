@@ -60,6 +60,15 @@ class MdpRaycasterDesc(C.Structure):
     ]
 
 
+class MdpHeightScanObs(C.Structure):
+    """Mirror of ``mdp_height_scan_obs_t``."""
+
+    _fields_ = [
+        ("obs", C.c_void_p), ("ld_obs", C.c_int32), ("col_offset", C.c_int32), ("offset", C.c_float),
+        ("pad0", C.c_int32), ("rng", C.c_void_p), ("post", MdpTerm),
+    ]
+
+
 class MdpVelocityCommandCfg(C.Structure):
     _fields_ = [
         ("resampling_time_lo", C.c_float), ("resampling_time_hi", C.c_float),

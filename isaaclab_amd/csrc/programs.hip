@@ -12,6 +12,7 @@
 #include "raycast_device.hpp"
 #include "mesh_handle.hpp"
 #include "term_ops.h"
+#include "obs_post_device.hpp"
 
 #include <cstdlib>
 #include <vector>
@@ -181,32 +182,6 @@ MDP_DEV void obs_cast_commit(const mdp_term_t& t, int e) {
     if (d.is_outdated) d.is_outdated[e] = 0;
 }
 
-// observation_manager.py:313-318: noise -> clip -> scale
-MDP_DEV float obs_post(const mdp_term_t& t, float v, int e, int k, uint64_t seed, uint64_t epoch, uint32_t stream,
-                       uint64_t index) {
-    if (t.noise_kind == 1) {
-        float u = t.noise_u ? t.noise_u[(int64_t)e * t.dim + k] : rng_uniform(seed, epoch, stream, index);
-        float n = u * t.n1;  // n1 = (n_max - n_min)
-        if (t.noise_op == 0) v = (v + n) + t.n0;
-        else if (t.noise_op == 1) v = v * (n + t.n0);
-        else v = n + t.n0;
-    } else if (t.noise_kind == 2) {
-        float z = t.noise_u ? t.noise_u[(int64_t)e * t.dim + k] : rng_normal(seed, epoch, stream, index);
-        float n = t.n1 * z;  // std * randn
-        if (t.noise_op == 0) v = (v + t.n0) + n;
-        else if (t.noise_op == 1) v = v * (t.n0 + n);
-        else v = t.n0 + n;
-    } else if (t.noise_kind == 3) {
-        if (t.noise_op == 0) v = v + t.n0;
-        else if (t.noise_op == 1) v = v * t.n0;
-        else v = 0.0f + t.n0;
-    }
-    if (t.has_clip) v = tclamp(v, t.clip_lo, t.clip_hi);
-    if (t.has_scale == 1) v = v * t.scale;
-    else if (t.has_scale == 2) v = v * t.scale_vec[k];
-    return v;
-}
-
 constexpr int OBS_POSE_SLOTS = 32;  // env slots per block whose sensor pose is staged in LDS
 
 // Every lane of a wave walks a different column, so term records would be fetched with per-lane (vector) global
@@ -255,6 +230,7 @@ __global__ void k_obs(const mdp_term_t* __restrict__ g_terms, int T, const int32
             for (int c = lc; c < O; c += slot_w) {
                 int ti = col2term[c];
                 const mdp_term_t& t = terms[ti];
+                if (t.op == MDP_OBS_SKIP) continue;   // written by another launch (mdp_raycaster_update epilogue)
                 int k = c - t.out_offset;
                 float v;
                 if (CAST && t.op == MDP_OBS_HEIGHT_SCAN_CAST) {

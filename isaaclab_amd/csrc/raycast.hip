@@ -5,6 +5,7 @@
 #include "mdp_host.hpp"
 #include "raycast_device.hpp"
 #include "mesh_handle.hpp"
+#include "obs_post_device.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -380,6 +381,14 @@ __device__ __forceinline__ mdp_hit_t rc_query(const mdp_mesh_view_t* m, const md
     return mdp_rc_brute(m, r, max_t);
 }
 
+// height_scan observation column of ray r of env e, written by the cast kernels (mdp_height_scan_obs_t)
+__device__ __forceinline__ void scan_store(const mdp_height_scan_obs_t& sc, int e, int r, int R, float sensor_z, float hit_z,
+                                           uint64_t seed, uint64_t epoch) {
+    float v = (sensor_z - hit_z) - sc.offset;   // observations.py:173
+    v = obs_post(sc.post, v, e, r, seed, epoch, 0x48534341u, (uint64_t)e * (uint64_t)R + (uint64_t)r);
+    sc.obs[(int64_t)e * sc.ld_obs + sc.col_offset + r] = v;
+}
+
 // ops.py:61-127 + kernels.py:55-75: one thread per ray
 template <int ACCEL>
 __global__ void k_raycast(mdp_mesh_view_t mesh, int64_t num_rays, const float* __restrict__ starts,
@@ -423,15 +432,21 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
                                    int yaw_only, float max_dist, float* __restrict__ pos_w,
                                    float* __restrict__ quat_w, float* __restrict__ hits,
                                    const float* __restrict__ ts, float* __restrict__ ts_last,
-                                   uint8_t* __restrict__ outdated) {
+                                   uint8_t* __restrict__ outdated, mdp_height_scan_obs_t scan) {
     const float inf = __builtin_inff();
     int le = threadIdx.x / slot_w;
     int lr = threadIdx.x - le * slot_w;
+    uint64_t seed = 0, epoch = 0;
+    if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + blockIdx.x]; }
     for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
         int e = base + le;
         bool active = le < epb && e < N;
         bool od = active && (outdated ? outdated[e] != 0 : true);
         __syncthreads();
+        if (active && !od && scan.obs) {
+            float sz = pos_w[3 * (int64_t)e + 2];
+            for (int r = lr; r < R; r += slot_w) scan_store(scan, e, r, R, sz, hits[((int64_t)e * R + r) * 3 + 2], seed, epoch);
+        }
         if (od) {
             const float* p = pose + (int64_t)e * ld_pose;
             V3 pos = ld3(p);
@@ -446,11 +461,14 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
                 mdp_ray_t ray = mdp_rc_make_ray(s.x, s.y, s.z, d.x, d.y, d.z);
                 mdp_hit_t h = rc_query<ACCEL>(&mesh, &ray, max_dist);
                 float* o = hits + ((int64_t)e * R + r) * 3;
+                float hz = inf;
                 if (h.face >= 0) {
-                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = s.z + h.t * d.z;
+                    hz = s.z + h.t * d.z;
+                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = hz;
                 } else {
                     o[0] = inf; o[1] = inf; o[2] = inf;
                 }
+                if (scan.obs) scan_store(scan, e, r, R, pos.z, hz, seed, epoch);
             }
             if (lr == 0) {
                 st3(pos_w + 3 * (int64_t)e, pos);
@@ -460,6 +478,7 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
             }
         }
     }
+    if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + blockIdx.x] = epoch + 1;
 }
 
 // The height-scan case of k_raycaster_update: yaw-only attachment and a pattern whose directions are all (0, 0, -c),
@@ -471,15 +490,21 @@ k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w,
                         int ld_pose, const float* __restrict__ drift, const float* __restrict__ starts_l,
                         const float* __restrict__ dirs_l, float max_dist, float* __restrict__ pos_w,
                         float* __restrict__ quat_w, float* __restrict__ hits, const float* __restrict__ ts,
-                        float* __restrict__ ts_last, uint8_t* __restrict__ outdated) {
+                        float* __restrict__ ts_last, uint8_t* __restrict__ outdated, mdp_height_scan_obs_t scan) {
     const float inf = __builtin_inff();
     int le = threadIdx.x / slot_w;
     int lr = threadIdx.x - le * slot_w;
+    uint64_t seed = 0, epoch = 0;
+    if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + blockIdx.x]; }
     for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
         int e = base + le;
         bool active = le < epb && e < N;
         bool od = active && (outdated ? outdated[e] != 0 : true);
         __syncthreads();
+        if (active && !od && scan.obs) {
+            float sz = pos_w[3 * (int64_t)e + 2];
+            for (int r = lr; r < R; r += slot_w) scan_store(scan, e, r, R, sz, hits[((int64_t)e * R + r) * 3 + 2], seed, epoch);
+        }
         if (od) {
             const float* p = pose + (int64_t)e * ld_pose;
             V3 pos = ld3(p);
@@ -493,11 +518,14 @@ k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w,
                 mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
                 mdp_hit_t h = mdp_rc_grid_down<BATCH>(&mesh, &ray, max_dist);
                 float* o = hits + ((int64_t)e * R + r) * 3;
+                float hz = inf;
                 if (h.face >= 0) {
-                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = s.z + h.t * d.z;
+                    hz = s.z + h.t * d.z;
+                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = hz;
                 } else {
                     o[0] = inf; o[1] = inf; o[2] = inf;
                 }
+                if (scan.obs) scan_store(scan, e, r, R, pos.z, hz, seed, epoch);
             }
             if (lr == 0) {
                 st3(pos_w + 3 * (int64_t)e, pos);
@@ -507,6 +535,7 @@ k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w,
             }
         }
     }
+    if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + blockIdx.x] = epoch + 1;
 }
 
 }  // namespace
@@ -533,7 +562,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
                                     const float* ray_dirs_local, int attach_yaw_only, int pattern_vertical_down,
                                     float max_dist, float* pos_w, float* quat_w, float* ray_hits_w,
                                     const float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
-                                    void* stream) {
+                                    const mdp_height_scan_obs_t* scan, void* stream) {
     MDP_REQUIRE(mesh && root_pose && ray_starts_local && ray_dirs_local && pos_w && quat_w && ray_hits_w,
                 "null pointer");
     MDP_REQUIRE(ld_pose >= 7, "root_pose must be (N,>=7)");
@@ -543,13 +572,24 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     int slot_w = num_rays >= 256 ? 256 : num_rays;
     int threads = ((epb * slot_w + 63) / 64) * 64;
     int64_t blocks = ((int64_t)num_envs + epb - 1) / epb;
+    mdp_height_scan_obs_t sc;
+    std::memset(&sc, 0, sizeof(sc));
+    if (scan && scan->obs) {
+        MDP_REQUIRE(scan->ld_obs >= scan->col_offset + num_rays && scan->col_offset >= 0,
+                    "height-scan columns [%d, %d) do not fit the observation row (%d)", scan->col_offset,
+                    scan->col_offset + num_rays, scan->ld_obs);
+        const bool generated = (scan->post.noise_kind == 1 || scan->post.noise_kind == 2) && !scan->post.noise_u;
+        MDP_REQUIRE(!generated || scan->rng, "generated noise needs the rng words");
+        sc = *scan;
+        if (!generated) sc.rng = nullptr;
+    }
     if (pattern_vertical_down && attach_yaw_only && mesh->view.accel == 1 && mesh->view.cell_recs) {
         static const int batch = [] { const char* b = std::getenv("MDP_RC_BATCH"); return b ? std::atoi(b) : 2; }();
 #define RCD_LAUNCH(B)                                                                                             \
     hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,          \
                        as_stream(stream), mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift,  \
                        ray_starts_local, ray_dirs_local, max_dist, pos_w, quat_w, ray_hits_w, timestamp,           \
-                       timestamp_last_update, is_outdated)
+                       timestamp_last_update, is_outdated, sc)
         if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
 #undef RCD_LAUNCH
         MDP_LAUNCH_CHECK();
@@ -559,7 +599,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     hipLaunchKernelGGL(k_raycaster_update<A>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,               \
                        as_stream(stream), mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift,  \
                        ray_starts_local, ray_dirs_local, attach_yaw_only, max_dist, pos_w, quat_w, ray_hits_w,     \
-                       timestamp, timestamp_last_update, is_outdated)
+                       timestamp, timestamp_last_update, is_outdated, sc)
     if (mesh->view.accel == 2) RCU_LAUNCH(2); else if (mesh->view.accel == 1) RCU_LAUNCH(1); else RCU_LAUNCH(0);
 #undef RCU_LAUNCH
     MDP_LAUNCH_CHECK();

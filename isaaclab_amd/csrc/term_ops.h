@@ -15,7 +15,8 @@
 #define MDP_OBS_HEIGHT_SCAN 7              /* :165-173, reads the sensor buffers */
 #define MDP_OBS_HEIGHT_SCAN_CAST 8         /* :165-173 fused with ray_caster.py:220-260 */
 #define MDP_OBS_ADD_ROW_BIAS 9            /* p0[e*i0 + i1 + idx(k)] + p1[e*i2 + i3]  (noise_model.py:173-182) */
-#define MDP_OBS_NUM_OPS 10
+#define MDP_OBS_SKIP 10                    /* columns written by another launch (height scan from the cast kernel) */
+#define MDP_OBS_NUM_OPS 11
 
 /* ---- reward ops: one scalar per env --------------------------------------------------------- */
 #define MDP_REW_EXTERNAL 0

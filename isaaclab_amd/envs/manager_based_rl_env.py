@@ -122,16 +122,25 @@ class ManagerBasedRLEnv:
             # go to two streams (two branches of a captured hipGraph) and join before the observations.
             main = torch.cuda.current_stream(self.device)
             side = self._side_stream
+            om = self.observation_manager
+            split = om.can_split_sensor_terms()   # sensor-owned obs columns (height scan) come from the cast kernel
             self._ev_scene.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(self._ev_scene)
                 self._termination_reward_fused()
                 self.command_manager.compute(dt=self.step_dt)   # after the rewards: they read the previous command
+                if split:
+                    self.obs_buf = om.compute(skip_sensor_terms=True)
                 self._ev_side.record(side)
-            for sensor in self.scene.sensors.values():      # lazily evaluated sensors the observations will read
-                if hasattr(sensor, "fill_scene_tick"):
-                    sensor._update_outdated_buffers()
+            if split:
+                om.compute_sensor_terms()
+            else:
+                for sensor in self.scene.sensors.values():  # lazily evaluated sensors the observations will read
+                    if hasattr(sensor, "fill_scene_tick"):
+                        sensor._update_outdated_buffers()
             main.wait_event(self._ev_side)
+            if not split:
+                self.obs_buf = om.compute()
         else:
             if self.fuse_post_physics and self._can_fuse_post_physics():
                 self._termination_reward_fused()
@@ -139,15 +148,14 @@ class ManagerBasedRLEnv:
                 self.episode_length_buf += 1
                 self.reset_buf = self.termination_manager.compute()
                 self.reward_buf = self.reward_manager.compute(dt=self.step_dt)
-        self.reset_terminated = self.termination_manager.terminated
-        self.reset_time_outs = self.termination_manager.time_outs
-        if not concurrent:
             if self.auto_reset:
                 reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
                 if len(reset_env_ids) > 0:
                     self._reset_idx(reset_env_ids)
             self.command_manager.compute(dt=self.step_dt)
-        self.obs_buf = self.observation_manager.compute()
+            self.obs_buf = self.observation_manager.compute()
+        self.reset_terminated = self.termination_manager.terminated
+        self.reset_time_outs = self.termination_manager.time_outs
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
 
     def _can_fuse_post_physics(self) -> bool:

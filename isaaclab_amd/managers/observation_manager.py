@@ -31,6 +31,8 @@ class ObservationManager(ManagerBase):
             raise ValueError("Observation manager configuration is None. Please provide a valid configuration.")
         self._seed = seed
         self._programs: dict[str, Program | None] = {}
+        self._scans: dict[str, list] = {}
+        self._skip_sensor_terms = False
         super().__init__(cfg, env)
         self._group_obs_dim: dict[str, tuple[int, ...] | list[tuple[int, ...]]] = dict()
         for group_name, group_term_dims in self._group_obs_term_dim.items():
@@ -110,10 +112,16 @@ class ObservationManager(ManagerBase):
             mod.reset(env_ids=env_ids)
         return {}
 
-    def compute(self):
+    def compute(self, skip_sensor_terms: bool = False):
+        """observation_manager.py:238-258.  ``skip_sensor_terms``: the caller has launched ``compute_sensor_terms()``
+        itself (on another stream)."""
         obs_buffer = dict()
-        for group_name in self._group_obs_term_names:
-            obs_buffer[group_name] = self.compute_group(group_name)
+        self._skip_sensor_terms = skip_sensor_terms
+        try:
+            for group_name in self._group_obs_term_names:
+                obs_buffer[group_name] = self.compute_group(group_name)
+        finally:
+            self._skip_sensor_terms = False
         self._obs_buffer = obs_buffer
         return obs_buffer
 
@@ -134,6 +142,7 @@ class ObservationManager(ManagerBase):
         offset = 0
         self._external[group_name] = []
         offsets = []
+        scans: list = []
         for term_cfg, dims in zip(cfgs, self._group_obs_term_dim[group_name]):
             dim = int(np.prod(dims))
             lower = getattr(term_cfg.func, "lower", None)
@@ -142,6 +151,15 @@ class ObservationManager(ManagerBase):
                 if spec.op == "MDP_OBS_HEIGHT_SCAN" and spec.raycaster is not None and spec.raycaster.can_fuse:
                     spec.op = "MDP_OBS_HEIGHT_SCAN_CAST"
                     spec.before = []
+                elif (spec.op == "MDP_OBS_HEIGHT_SCAN" and spec.raycaster is not None
+                      and getattr(spec.raycaster, "scan_in_cast", False) and dim == spec.raycaster.num_rays):
+                    # the cast kernel writes these columns (mdp_height_scan_obs_t); the program skips them
+                    scan = L.MdpHeightScanObs()
+                    scan.col_offset, scan.offset = offset, float(spec.f.get(0, 0.5))
+                    scans.append((spec.raycaster, scan, len(specs)))
+                    spec.op = "MDP_OBS_SKIP"
+                    spec.before = []
+                    spec.p = {}
             else:
                 staging = torch.zeros((self.num_envs, dim), dtype=torch.float32, device=self.device)
                 self._external[group_name].append((term_cfg, staging))
@@ -168,8 +186,22 @@ class ObservationManager(ManagerBase):
                 else:
                     t.has_scale, t.scale = 1, float(cfg.scale)
 
+            for _, scan, term_index in scans:
+                if term_index == n:
+                    # the cast kernel applies this term's noise / clip / scale
+                    for name in ("dim", "noise_kind", "noise_op", "n0", "n1", "noise_u", "has_clip", "clip_lo", "clip_hi",
+                                 "has_scale", "scale", "scale_vec"):
+                        setattr(scan.post, name, getattr(t, name))
+
         seed = self._seed if self._seed is not None else torch.initial_seed()
-        return Program(OBS, self.num_envs, self.device, specs, structs_post=post, seed=seed)
+        prog = Program(OBS, self.num_envs, self.device, specs, structs_post=post, seed=seed)
+        for k, (_, scan, _) in enumerate(scans):
+            rng = torch.zeros(1 + self.num_envs, dtype=torch.int64, device=self.device)
+            rng[0] = (seed + 7919 * (k + 1)) & 0x7FFFFFFFFFFFFFFF
+            scan.rng = rng.data_ptr()
+            self._keepalive.append(rng)
+        self._scans[group_name] = [(sensor, scan) for sensor, scan, _ in scans]
+        return prog
 
     def _compute_group_fused(self, group_name: str) -> torch.Tensor:
         prog = self._programs.get(group_name)
@@ -186,8 +218,35 @@ class ObservationManager(ManagerBase):
             out = torch.empty((self.num_envs, width), dtype=torch.float32, device=self.device)
             if self.persistent_output:
                 self._out_buffers[group_name] = out
+        if not self._skip_sensor_terms:
+            self._launch_scans(group_name, out, width)
         L.check(L.lib.mdp_obs_compute(prog.handle, out.data_ptr(), width, L.stream(self.device)))
         return out
+
+    def _launch_scans(self, group_name: str, out: torch.Tensor, width: int):
+        for sensor, scan in self._scans.get(group_name, []):
+            scan.obs, scan.ld_obs = out.data_ptr(), width
+            sensor._update_outdated_buffers(scan=scan)
+
+    def can_split_sensor_terms(self) -> bool:
+        """Whether ``compute_sensor_terms()`` + ``compute(skip_sensor_terms=True)`` can replace ``compute()``: every
+        group is fused, its program is built and its output buffer is persistent."""
+        if not self.persistent_output:
+            return False
+        for group_name in self._group_obs_term_names:
+            if not self._group_fusable[group_name]:
+                return False
+            if self._programs.get(group_name) is None or group_name not in self._out_buffers:
+                return False
+        return True
+
+    def compute_sensor_terms(self):
+        """Launches only the sensor-owned observation columns (height scans written by their cast kernels) of every
+        group into the persistent output buffers; ``compute(skip_sensor_terms=True)`` evaluates the rest.  Lets a caller
+        put the two on different streams (``can_split_sensor_terms()`` must hold)."""
+        for group_name in self._group_obs_term_names:
+            out = self._out_buffers[group_name]
+            self._launch_scans(group_name, out, out.shape[1])
 
     # -- term-by-term path -------------------------------------------------------------------------
     def _compute_group_unfused(self, group_name: str):

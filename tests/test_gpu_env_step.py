@@ -10,7 +10,7 @@ from conftest import assert_close, to_np
 pytestmark = pytest.mark.gpu
 
 
-def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, **kw):
+def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, persistent=False, scan_in_cast=None, **kw):
     import torch
 
     from isaaclab_amd.envs.synthetic import make_velocity_env
@@ -18,6 +18,10 @@ def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, **kw):
     env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=seed, **kw)
     if fuse_cast is not None:
         env.scene.sensors["height_scanner"].fuse_into_observations = fuse_cast
+    if scan_in_cast is not None:
+        env.scene.sensors["height_scanner"].scan_in_cast = scan_in_cast
+    # persistent observation buffers let the step put the sensor-owned columns and the rest on two streams
+    env.observation_manager.persistent_output = persistent
     if not fused:      # the per-entity / per-manager launches of the reference call structure
         env.scene.fused_update = False
         env.fuse_post_physics = False
@@ -50,14 +54,18 @@ def test_anymal_d_flat(device, n):
     compare(outs, replay_oracle(rec, 6))
 
 
-@pytest.mark.parametrize("n,fuse_cast,fused", ((5, False, True), (128, False, True), (128, True, True), (37, False, False)))
-def test_anymal_d_rough(device, n, fuse_cast, fused):
+@pytest.mark.parametrize("n,fuse_cast,fused,persistent,scan_in_cast",
+                         ((5, False, True, False, True), (128, False, True, True, True), (128, True, True, False, True),
+                          (37, False, False, False, True), (64, False, True, True, False)))
+def test_anymal_d_rough(device, n, fuse_cast, fused, persistent, scan_in_cast):
     """BASELINE config C2 (rough, 187-ray height scan, 235-dim observation): the default launch structure (fused
     scene update, fused termination + reward, vertical-ray cast kernel + lean observation kernel), the height scan
-    cast inside the observation kernel, and the unfused per-entity / per-manager launches."""
+    cast inside the observation kernel, the unfused per-entity / per-manager launches, persistent observation buffers
+    (two-stream split of the observation) and the height scan read back from the sensor buffers."""
     from oracle.harness import replay_oracle
 
-    env, rec, outs = run_env("anymal_d_rough", n, 6, device, seed=12, small_terrain=True, fuse_cast=fuse_cast, fused=fused)
+    env, rec, outs = run_env("anymal_d_rough", n, 6, device, seed=12, small_terrain=True, fuse_cast=fuse_cast, fused=fused,
+                              persistent=persistent, scan_in_cast=scan_in_cast)
     assert outs[0][0].shape == (n, 235)
     compare(outs, replay_oracle(rec, 6))
     # sensor state after the run.  The rays themselves come from quat_apply_yaw on device vs host libm (1-ulp
@@ -93,7 +101,7 @@ def test_anymal_c_rough_lstm(device):
     """BASELINE metric configuration: rough terrain + ANYdrive LSTM actuator net (seeded random weights)."""
     from oracle.harness import replay_oracle
 
-    env, rec, outs = run_env("anymal_c_rough", 96, 5, device, seed=14, small_terrain=True)
+    env, rec, outs = run_env("anymal_c_rough", 96, 5, device, seed=14, small_terrain=True, persistent=True)
     assert outs[0][0].shape == (96, 235)
     ref = replay_oracle(rec, 5)
     # the MFMA LSTM sums in a different order than numpy: torques agree to ~1e-5 abs, which the
