@@ -47,7 +47,7 @@ def parse():
     p.add_argument("--ring", type=int, default=32, help="env-steps in the replayed frame ring (x decimation frames)")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=24)
+    p.add_argument("--cpu-steps", type=int, default=128, help="env-steps of the CPU baseline sample (~15 s)")
     p.add_argument("--stats-every", type=int, default=24, help="rollout length between episode-stat all-reduces")
     p.add_argument("--small-terrain", action="store_true")
     p.add_argument("--fuse-cast", action="store_true", help="cast the height scan inside the observation kernel")
@@ -87,8 +87,9 @@ def algorithmic_bytes(env) -> dict:
         "command": (4 * 13 + 16 + 12, 1, "k_velocity_command"),  # root state; command RMW; timers
     }
     if R:
-        table["raycast"] = (4 * 7 + 12 * R + 28, 1, "k_raycaster_update")  # pose in; ray_hits + sensor pose out
-        table["observation"] = (4 * (13 + 3 * J + 3) + 4 * R + 4 * O, 1, "k_obs")  # state + hit heights in; obs out
+        # cast: pose in; ray_hits + sensor pose + the height-scan observation columns out (written by the cast kernel)
+        table["raycast"] = (4 * 7 + 12 * R + 28 + 4 * R, 1, "k_raycaster_update")
+        table["observation"] = (4 * (13 + 3 * J + 3) + 4 * (O - R), 1, "k_obs")  # state in; remaining columns out
     else:
         table["observation"] = (4 * (13 + 3 * J + 3) + 4 * O, 1, "k_obs")
     return table
@@ -262,13 +263,14 @@ def measure_roofline(env, args) -> dict:
     N = env.num_envs
     robot = env.scene["robot"]
     sensors = env.scene.sensors
+    split = env.observation_manager.can_split_sensor_terms()
     fns = {
         "actuator": lambda: robot.write_data_to_sim(),
         "scene_update": lambda: env.scene.update(env.physics_dt),
         "action": lambda: env.action_manager.process_action(env.action_manager.action),
         "term_reward": lambda: env._termination_reward_fused(),
         "command": lambda: env.command_manager.compute(dt=env.step_dt),
-        "observation": lambda: env.observation_manager.compute(),
+        "observation": lambda: env.observation_manager.compute(skip_sensor_terms=split),
     }
     fill_s = 0.0
     if "height_scanner" in sensors:
@@ -276,7 +278,10 @@ def measure_roofline(env, args) -> dict:
 
         def cast():                     # every timed launch must cast: re-arm the outdated flags first
             hs._is_outdated.fill_(True)
-            hs._update_outdated_buffers()
+            if split:
+                env.observation_manager.compute_sensor_terms()
+            else:
+                hs._update_outdated_buffers()
 
         fill_s = _graph_time(lambda: hs._is_outdated.fill_(True))
         fns["raycast"] = cast
@@ -301,12 +306,13 @@ def cpu_baseline(rec, args) -> dict:
 
     threads = int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or min(os.cpu_count() or 1, 16)
     orc = build_oracle(rec, threads=threads)
-    steps = min(args.cpu_steps, rec.actions.shape[0])
+    steps = args.cpu_steps
+    ring = rec.actions.shape[0]
     oracle_step(orc, rec, 0)                       # warm-up (page-in, OpenMP pool)
     orc = build_oracle(rec, threads=threads)
     t0 = time.perf_counter()
     for k in range(steps):
-        oracle_step(orc, rec, k)
+        oracle_step(orc, rec, k % ring)            # the same ring of frames the GPU replays
     dt = time.perf_counter() - t0
     return {"value": rec.num_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{steps} env-steps x {rec.num_envs} envs of the same workload and frames (numpy oracle; ray cast in C/OpenMP"

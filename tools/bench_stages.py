@@ -50,11 +50,11 @@ def stage_functions(env):
 
         def cast():
             hs._is_outdated.fill_(True)
-            hs._update_outdated_buffers()
+            env.observation_manager.compute_sensor_terms()
 
         fns["fill(1B x N)"] = lambda: hs._is_outdated.fill_(True)
         fns["fill+raycast"] = cast
-    fns["observation"] = lambda: env.observation_manager.compute()
+    fns["observation"] = lambda: env.observation_manager.compute(skip_sensor_terms=True)
     return fns
 
 
@@ -67,8 +67,6 @@ def main():
     env, rec = make_velocity_env(args.config, num_envs=args.envs, device="cuda:0", steps=4, seed=5,
                                  small_terrain=args.small_terrain, inject_random=False)
     env.observation_manager.persistent_output = True
-    if "height_scanner" in env.scene.sensors:
-        env.scene.sensors["height_scanner"].fuse_into_observations = False
     acts = rec.actions.to("cuda:0")
     for k in range(4):
         env.step(acts[k % acts.shape[0]])
