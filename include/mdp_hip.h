@@ -274,15 +274,20 @@ int mdp_raycast(const mdp_mesh_t* mesh, int64_t num_rays,
  * last_update = timestamp, outdated = 0.  root_pose: (N, >=7) [pos, quat wxyz] with row stride ld.
  * pattern_vertical_down != 0 is the caller's promise that every local direction is (0, 0, -c), c > 0 (the height-scan
  * grid pattern, patterns.py:42-56): with yaw-only attachment the rays are then vertical in the world and a
- * specialised kernel (same arithmetic, half the registers, one grid cell per ray) is used. */
+ * specialised kernel (same arithmetic, half the registers, one grid cell per ray) is used.
+ * pose_xyzw != 0: root_pose rows are the physics engine's (N,7) [pos, quat xyzw] transforms read in place
+ * (ray_caster.py:226-232) instead of (w,x,y,z) root-state rows.  tick_dt > 0: the kernel first performs this sensor's
+ * SensorBase.update(tick_dt) bookkeeping (timestamp += dt, outdated when update_period elapsed; sensor_base.py:197-205),
+ * so the cast of the last physics sub-step does not depend on the launch that updates the rest of the scene. */
 struct mdp_height_scan_obs;
 int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int num_rays,
                          const float* root_pose, int ld_pose, const float* drift,
                          const float* ray_starts_local, const float* ray_dirs_local,
                          int attach_yaw_only, int pattern_vertical_down, float max_dist,
                          float* pos_w, float* quat_w, float* ray_hits_w,
-                         const float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
-                         const struct mdp_height_scan_obs* scan, void* stream);
+                         float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
+                         const struct mdp_height_scan_obs* scan, int pose_xyzw, float tick_dt, float update_period,
+                         void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Manager term programs (LAB/managers/{observation,reward,termination}_manager.py,

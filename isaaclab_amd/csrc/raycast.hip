@@ -431,8 +431,9 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
                                    const float* __restrict__ starts_l, const float* __restrict__ dirs_l,
                                    int yaw_only, float max_dist, float* __restrict__ pos_w,
                                    float* __restrict__ quat_w, float* __restrict__ hits,
-                                   const float* __restrict__ ts, float* __restrict__ ts_last,
-                                   uint8_t* __restrict__ outdated, mdp_height_scan_obs_t scan) {
+                                   float* __restrict__ ts, float* __restrict__ ts_last,
+                                   uint8_t* __restrict__ outdated, mdp_height_scan_obs_t scan, int pose_xyzw,
+                                   float tick_dt, float period) {
     const float inf = __builtin_inff();
     int le = threadIdx.x / slot_w;
     int lr = threadIdx.x - le * slot_w;
@@ -441,6 +442,16 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
     for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
         int e = base + le;
         bool active = le < epb && e < N;
+        if (tick_dt > 0.0f) {
+            // SensorBase.update of this physics step (sensor_base.py:197-205) done here, so the cast does not have
+            // to wait for the launch that updates the rest of the scene
+            if (active && lr == 0) {
+                float t = ts[e] + tick_dt;
+                ts[e] = t;
+                if ((t - ts_last[e]) + 1e-6f >= period) outdated[e] = 1;
+            }
+            __syncthreads();
+        }
         bool od = active && (outdated ? outdated[e] != 0 : true);
         __syncthreads();
         if (active && !od && scan.obs) {
@@ -451,7 +462,8 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
             const float* p = pose + (int64_t)e * ld_pose;
             V3 pos = ld3(p);
             if (drift) { pos.x += drift[3 * e]; pos.y += drift[3 * e + 1]; pos.z += drift[3 * e + 2]; }
-            Q4 q = ld4(p + 3);
+            // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows are (w, x, y, z)
+            Q4 q = pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
             Q4 qr = yaw_only ? yaw_quat(q) : q;
             for (int r = lr; r < R; r += slot_w) {
                 V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
@@ -489,8 +501,9 @@ __global__ void __launch_bounds__(256)
 k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w, const float* __restrict__ pose,
                         int ld_pose, const float* __restrict__ drift, const float* __restrict__ starts_l,
                         const float* __restrict__ dirs_l, float max_dist, float* __restrict__ pos_w,
-                        float* __restrict__ quat_w, float* __restrict__ hits, const float* __restrict__ ts,
-                        float* __restrict__ ts_last, uint8_t* __restrict__ outdated, mdp_height_scan_obs_t scan) {
+                        float* __restrict__ quat_w, float* __restrict__ hits, float* __restrict__ ts,
+                        float* __restrict__ ts_last, uint8_t* __restrict__ outdated, mdp_height_scan_obs_t scan,
+                        int pose_xyzw, float tick_dt, float period) {
     const float inf = __builtin_inff();
     int le = threadIdx.x / slot_w;
     int lr = threadIdx.x - le * slot_w;
@@ -499,6 +512,16 @@ k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w,
     for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
         int e = base + le;
         bool active = le < epb && e < N;
+        if (tick_dt > 0.0f) {
+            // SensorBase.update of this physics step (sensor_base.py:197-205) done here, so the cast does not have
+            // to wait for the launch that updates the rest of the scene
+            if (active && lr == 0) {
+                float t = ts[e] + tick_dt;
+                ts[e] = t;
+                if ((t - ts_last[e]) + 1e-6f >= period) outdated[e] = 1;
+            }
+            __syncthreads();
+        }
         bool od = active && (outdated ? outdated[e] != 0 : true);
         __syncthreads();
         if (active && !od && scan.obs) {
@@ -509,7 +532,8 @@ k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w,
             const float* p = pose + (int64_t)e * ld_pose;
             V3 pos = ld3(p);
             if (drift) { pos.x += drift[3 * e]; pos.y += drift[3 * e + 1]; pos.z += drift[3 * e + 2]; }
-            Q4 q = ld4(p + 3);
+            // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows are (w, x, y, z)
+            Q4 q = pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
             Q4 qr = yaw_quat(q);
             for (int r = lr; r < R; r += slot_w) {
                 V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
@@ -561,12 +585,15 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
                                     int ld_pose, const float* drift, const float* ray_starts_local,
                                     const float* ray_dirs_local, int attach_yaw_only, int pattern_vertical_down,
                                     float max_dist, float* pos_w, float* quat_w, float* ray_hits_w,
-                                    const float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
-                                    const mdp_height_scan_obs_t* scan, void* stream) {
+                                    float* timestamp, float* timestamp_last_update, uint8_t* is_outdated,
+                                    const mdp_height_scan_obs_t* scan, int pose_xyzw, float tick_dt,
+                                    float update_period, void* stream) {
     MDP_REQUIRE(mesh && root_pose && ray_starts_local && ray_dirs_local && pos_w && quat_w && ray_hits_w,
                 "null pointer");
     MDP_REQUIRE(ld_pose >= 7, "root_pose must be (N,>=7)");
     MDP_REQUIRE((timestamp_last_update == nullptr) || timestamp, "timestamp required with timestamp_last_update");
+    MDP_REQUIRE(!(tick_dt > 0.0f) || (timestamp && timestamp_last_update && is_outdated),
+                "tick_dt needs timestamp, timestamp_last_update and is_outdated");
     if (num_envs == 0 || num_rays == 0) return MDP_OK;
     int epb = num_rays >= 256 ? 1 : 256 / num_rays;
     int slot_w = num_rays >= 256 ? 256 : num_rays;
@@ -589,7 +616,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,          \
                        as_stream(stream), mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift,  \
                        ray_starts_local, ray_dirs_local, max_dist, pos_w, quat_w, ray_hits_w, timestamp,           \
-                       timestamp_last_update, is_outdated, sc)
+                       timestamp_last_update, is_outdated, sc, pose_xyzw, tick_dt, update_period)
         if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
 #undef RCD_LAUNCH
         MDP_LAUNCH_CHECK();
@@ -599,7 +626,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     hipLaunchKernelGGL(k_raycaster_update<A>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,               \
                        as_stream(stream), mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift,  \
                        ray_starts_local, ray_dirs_local, attach_yaw_only, max_dist, pos_w, quat_w, ray_hits_w,     \
-                       timestamp, timestamp_last_update, is_outdated, sc)
+                       timestamp, timestamp_last_update, is_outdated, sc, pose_xyzw, tick_dt, update_period)
     if (mesh->view.accel == 2) RCU_LAUNCH(2); else if (mesh->view.accel == 1) RCU_LAUNCH(1); else RCU_LAUNCH(0);
 #undef RCU_LAUNCH
     MDP_LAUNCH_CHECK();

@@ -98,6 +98,12 @@ class ManagerBasedRLEnv:
         """manager_based_rl_env.py:152-241"""
         self.action_manager.process_action(action.to(self.device))
         decimation = self.cfg.decimation
+        concurrent = (self.concurrent_post_physics and not self.auto_reset and self._can_fuse_post_physics()
+                      and not self._post_physics_reads_lazy_sensor())
+        om = self.observation_manager
+        # sensor-owned observation columns (height scan) come from the cast kernel, on its own stream
+        split = concurrent and om.can_split_sensor_terms()
+        early_cast = split and self.scene.fused_update and len(om.scan_sensors()) > 0
         self.action_manager.apply_action()
         self.scene.write_data_to_sim()
         for k in range(decimation):
@@ -111,28 +117,30 @@ class ManagerBasedRLEnv:
                 else:
                     self.scene.update(dt=self.physics_dt)
                     self.scene.write_data_to_sim()
-            else:
+            elif not early_cast:
                 self.scene.update(dt=self.physics_dt)
         self.common_step_counter += 1
-        concurrent = (self.concurrent_post_physics and not self.auto_reset and self._can_fuse_post_physics()
-                      and not self._post_physics_reads_lazy_sensor())
         if concurrent:
             # Without the reset path between them (manager_based_rl_env.py:214-229) the chain terminations -> rewards ->
-            # command update and the height-scan cast only depend on the scene update above, not on each other: they
-            # go to two streams (two branches of a captured hipGraph) and join before the observations.
+            # command update -> observations and the height-scan cast do not depend on each other: they go to two
+            # streams (two branches of a captured hipGraph) and join at the end of the step.  The cast reads the sensor
+            # pose from the physics transforms and does its own update(dt) bookkeeping, so it only waits for the last
+            # physics step, not for the scene update (which moves to the other branch).
             main = torch.cuda.current_stream(self.device)
             side = self._side_stream
-            om = self.observation_manager
-            split = om.can_split_sensor_terms()   # sensor-owned obs columns (height scan) come from the cast kernel
             self._ev_scene.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(self._ev_scene)
+                if early_cast:
+                    self.scene.update(dt=self.physics_dt, skip_ticks=om.scan_sensors())
                 self._termination_reward_fused()
                 self.command_manager.compute(dt=self.step_dt)   # after the rewards: they read the previous command
                 if split:
                     self.obs_buf = om.compute(skip_sensor_terms=True)
                 self._ev_side.record(side)
-            if split:
+            if early_cast:
+                om.compute_sensor_terms(tick_dt=self.physics_dt, from_physics=True)
+            elif split:
                 om.compute_sensor_terms()
             else:
                 for sensor in self.scene.sensors.values():  # lazily evaluated sensors the observations will read

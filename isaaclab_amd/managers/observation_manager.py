@@ -223,10 +223,25 @@ class ObservationManager(ManagerBase):
         L.check(L.lib.mdp_obs_compute(prog.handle, out.data_ptr(), width, L.stream(self.device)))
         return out
 
-    def _launch_scans(self, group_name: str, out: torch.Tensor, width: int):
+    def _launch_scans(self, group_name: str, out: torch.Tensor, width: int, tick_dt: float = 0.0,
+                      from_physics: bool = False, ticked: set | None = None):
         for sensor, scan in self._scans.get(group_name, []):
             scan.obs, scan.ld_obs = out.data_ptr(), width
-            sensor._update_outdated_buffers(scan=scan)
+            dt = tick_dt
+            if ticked is not None:          # a sensor shared by several groups is ticked by its first launch only
+                if id(sensor) in ticked:
+                    dt = 0.0
+                ticked.add(id(sensor))
+            sensor._update_outdated_buffers(scan=scan, tick_dt=dt, from_physics=from_physics)
+
+    def scan_sensors(self) -> list:
+        """Sensors whose observation columns are written by their own cast kernel."""
+        out = []
+        for scans in self._scans.values():
+            for sensor, _ in scans:
+                if not any(sensor is s for s in out):
+                    out.append(sensor)
+        return out
 
     def can_split_sensor_terms(self) -> bool:
         """Whether ``compute_sensor_terms()`` + ``compute(skip_sensor_terms=True)`` can replace ``compute()``: every
@@ -240,13 +255,15 @@ class ObservationManager(ManagerBase):
                 return False
         return True
 
-    def compute_sensor_terms(self):
+    def compute_sensor_terms(self, tick_dt: float = 0.0, from_physics: bool = False):
         """Launches only the sensor-owned observation columns (height scans written by their cast kernels) of every
         group into the persistent output buffers; ``compute(skip_sensor_terms=True)`` evaluates the rest.  Lets a caller
-        put the two on different streams (``can_split_sensor_terms()`` must hold)."""
+        put the two on different streams (``can_split_sensor_terms()`` must hold).  ``tick_dt`` / ``from_physics``:
+        see ``RayCaster._update_outdated_buffers`` (the caller then leaves these sensors out of ``scene.update``)."""
+        ticked: set = set()
         for group_name in self._group_obs_term_names:
             out = self._out_buffers[group_name]
-            self._launch_scans(group_name, out, out.shape[1])
+            self._launch_scans(group_name, out, out.shape[1], tick_dt, from_physics, ticked)
 
     # -- term-by-term path -------------------------------------------------------------------------
     def _compute_group_unfused(self, group_name: str):

@@ -45,12 +45,14 @@ class InteractiveScene:
         for obj in self.rigid_objects.values():
             obj.write_data_to_sim()
 
-    def update(self, dt: float) -> None:
+    def update(self, dt: float, skip_ticks=()) -> None:
         """interactive_scene.py:496-513.  With one articulation and sensors that know how to describe their share
         (``fill_scene_update`` / ``fill_scene_tick``) the whole fan-out is ONE kernel launch (``mdp_scene_update``);
         anything else goes through the per-entity ``update`` calls below."""
-        if self.fused_update and self._update_fused(dt):
+        if self.fused_update and self._update_fused(dt, skip_ticks):
             return
+        if skip_ticks:
+            raise RuntimeError("skip_ticks needs the fused scene update")
         for articulation in self.articulations.values():
             articulation.update(dt)
         for obj in self.rigid_objects.values():
@@ -58,8 +60,9 @@ class InteractiveScene:
         for sensor in self.sensors.values():
             sensor.update(dt, force_recompute=not self.lazy_sensor_update)
 
-    def _scene_update_desc(self, dt: float):
-        """Descriptor of the fused post-physics launch, or None when some entity cannot describe its share."""
+    def _scene_update_desc(self, dt: float, skip_ticks=()):
+        """Descriptor of the fused post-physics launch, or None when some entity cannot describe its share.
+        ``skip_ticks``: lazily evaluated sensors whose bookkeeping the caller does itself (cast kernel pre-tick)."""
         from .. import _lib as L
 
         if len(self.articulations) != 1 or self.rigid_objects:
@@ -76,6 +79,8 @@ class InteractiveScene:
                     return None
                 seen_contact = True
             elif hasattr(sensor, "fill_scene_tick"):
+                if any(sensor is sk for sk in skip_ticks):
+                    continue
                 if not sensor.fill_scene_tick(d, force):
                     return None
             else:
@@ -83,12 +88,12 @@ class InteractiveScene:
         art.data.fill_scene_update(d, dt)
         return d, art
 
-    def _update_fused(self, dt: float) -> bool:
+    def _update_fused(self, dt: float, skip_ticks=()) -> bool:
         import ctypes as C
 
         from .. import _lib as L
 
-        plan = self._scene_update_desc(dt)
+        plan = self._scene_update_desc(dt, skip_ticks)
         if plan is None:
             return False
         d, art = plan

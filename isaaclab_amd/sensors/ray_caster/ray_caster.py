@@ -141,18 +141,28 @@ class RayCaster(SensorBase):
         """Hook run before a fused program launch: makes sure the wxyz pose buffer is current."""
         self._pose()
 
-    def _update_outdated_buffers(self, scan=None):
+    def _update_outdated_buffers(self, scan=None, tick_dt: float = 0.0, from_physics: bool = False):
         """Casts the outdated envs.  ``scan`` (``L.MdpHeightScanObs``) additionally makes the kernel write the
-        post-processed ``height_scan`` observation columns of every env (``ObservationManager`` binds it)."""
+        post-processed ``height_scan`` observation columns of every env (``ObservationManager`` binds it).
+        ``tick_dt`` > 0 folds this physics step's ``update(dt)`` bookkeeping into the launch and ``from_physics`` reads
+        the sensor pose from the physics view's transforms in place (ray_caster.py:226-232) instead of a packed
+        root-state row: together they make the cast independent of the launch that updates the rest of the scene."""
         import ctypes as C
 
-        pose = self._pose()
+        if from_physics:
+            pose = self._view.get_root_transforms()
+            pose_ptr, ld, xyzw = pose.data_ptr(), pose.stride(0), 1
+        else:
+            pose = self._pose()
+            pose_ptr, ld, xyzw = pose.data_ptr(), pose.stride(0), 0
         L.check(L.lib.mdp_raycaster_update(
-            self._mesh.handle, self._num_envs, self.num_rays, pose.data_ptr(), pose.stride(0), self.drift.data_ptr(),
+            self._mesh.handle, self._num_envs, self.num_rays, pose_ptr, ld, self.drift.data_ptr(),
             self._ray_starts_local.data_ptr(), self._ray_dirs_local.data_ptr(), 1 if self.cfg.attach_yaw_only else 0,
-            1 if self._pattern_vertical_down else 0, float(self.cfg.max_distance), self._data.pos_w.data_ptr(), self._data.quat_w.data_ptr(),
+            1 if self._pattern_vertical_down else 0, float(self.cfg.max_distance),
+            self._data.pos_w.data_ptr(), self._data.quat_w.data_ptr(),
             self._data.ray_hits_w.data_ptr(), self._timestamp.data_ptr(), self._timestamp_last_update.data_ptr(),
-            self._is_outdated.data_ptr(), C.byref(scan) if scan is not None else None, L.stream()))
+            self._is_outdated.data_ptr(), C.byref(scan) if scan is not None else None, xyzw, float(tick_dt),
+            float(self.cfg.update_period), L.stream()))
 
 
 @configclass

@@ -302,6 +302,28 @@ def transform_points(points: torch.Tensor, pos: torch.Tensor | None = None, quat
 
 # -- samplers (math.py:1233-1421): RNG-consuming, distribution parity only ------------------------
 
+def sample_triangle(lower: float, upper: float, size, device) -> torch.Tensor:
+    """math.py:1287-1310: triangular law on [lower, upper] from one uniform draw of the torch generator (reset-time
+    sampler: it consumes the global generator exactly like the reference, so it stays a torch op)."""
+    if isinstance(size, int):
+        size = (size,)
+    u = 2.0 * torch.rand(*size, device=device) - 1.0
+    tri = torch.sign(u) * torch.sqrt(torch.abs(u))
+    return (upper - lower) * ((tri + 1.0) / 2.0) + lower
+
+
+def sample_cylinder(radius: float, h_range, size, device) -> torch.Tensor:
+    """math.py:1384-1421: points on the lateral surface of a z-aligned cylinder; angle first, then height, in the
+    reference's draw order."""
+    shape = (size,) if isinstance(size, int) else tuple(size)
+    angles = (torch.rand(shape, device=device) * 2.0 - 1.0) * math.pi
+    xyz = torch.zeros(shape + (3,), device=device)
+    xyz[..., 0] = radius * torch.cos(angles)
+    xyz[..., 1] = radius * torch.sin(angles)
+    xyz[..., 2].uniform_(h_range[0], h_range[1])
+    return xyz
+
+
 def sample_uniform(lower, upper, size, device) -> torch.Tensor:
     if isinstance(size, int):
         size = (size,)
