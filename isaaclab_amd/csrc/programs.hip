@@ -15,6 +15,7 @@
 #include "obs_post_device.hpp"
 
 #include <cstdlib>
+#include <algorithm>
 #include <vector>
 
 using namespace mdp;
@@ -32,6 +33,7 @@ struct mdp_program {
     int16_t* d_col2term = nullptr;
     uint64_t* d_rng = nullptr;  // {seed, per-block epoch counters}
     int total_cols = 0;
+    int active_cols = 0;  // columns up to the last one this program writes itself (trailing MDP_OBS_SKIP terms excluded)
     int uses_rng = 0;
     int has_cast = 0;
     int cast_ti = -1;  // first fused ray-cast term (its sensor pose is staged in LDS)
@@ -706,6 +708,7 @@ extern "C" int mdp_program_create(int kind, int device, int num_envs, const mdp_
             if (t.out_offset + t.dim > 32767 * 4) { delete p; return fail(MDP_ERR_INVALID, "observation too wide"); }
             if ((int)col2term.size() < t.out_offset + t.dim) col2term.resize(t.out_offset + t.dim, -1);
             for (int k = 0; k < t.dim; ++k) col2term[t.out_offset + k] = (int16_t)i;
+            if (t.op != MDP_OBS_SKIP && t.out_offset + t.dim > p->active_cols) p->active_cols = t.out_offset + t.dim;
             if (t.noise_kind == 1 || t.noise_kind == 2) p->uses_rng |= (t.noise_u == nullptr);
             if (t.op == MDP_OBS_HEIGHT_SCAN_CAST) {
                 const mdp_raycaster_desc_t* d = (const mdp_raycaster_desc_t*)t.p4;
@@ -754,7 +757,7 @@ extern "C" int mdp_program_create(int kind, int device, int num_envs, const mdp_
     }
     {
         // {seed, epoch of block 0, epoch of block 1, ...}: one counter per block of the observation grid
-        std::vector<uint64_t> rng((size_t)1 + obs_grid(p->num_envs, p->total_cols), 0);
+        std::vector<uint64_t> rng((size_t)1 + std::max(obs_grid(p->num_envs, p->total_cols), obs_grid(p->num_envs, p->active_cols)), 0);
         rng[0] = seed;
         MDP_CHECK_HIP(dmalloc((void**)&p->d_rng, sizeof(uint64_t) * rng.size()));
         MDP_CHECK_HIP(hipMemcpy(p->d_rng, rng.data(), sizeof(uint64_t) * rng.size(), hipMemcpyHostToDevice));
@@ -778,8 +781,9 @@ extern "C" int mdp_program_destroy(mdp_program_t* p) {
 extern "C" int mdp_obs_compute(mdp_program_t* p, float* obs, int ld_obs, void* stream) {
     MDP_REQUIRE(p && p->kind == MDP_PROG_OBS, "not an observation program");
     MDP_REQUIRE(obs && ld_obs >= p->total_cols, "obs buffer too narrow (%d < %d)", ld_obs, p->total_cols);
-    if (p->num_envs == 0 || p->total_cols == 0) return MDP_OK;
-    int O = p->total_cols;
+    if (p->num_envs == 0 || p->total_cols == 0 || p->active_cols == 0) return MDP_OK;
+    // columns behind the last one this program writes (height scans written by their cast kernels) get no threads
+    int O = p->active_cols;
     int epb = O >= 256 ? 1 : 256 / O;
     int slot_w = O >= 256 ? 256 : O;
     int threads = ((epb * slot_w + 63) / 64) * 64;
