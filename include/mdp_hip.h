@@ -553,6 +553,81 @@ int mdp_stats_moments(const float* x, int num_envs, int dim, int ld, double* out
 int mdp_stats_masked_sums(const float* values, int rows, int num_envs, const uint8_t* mask, double* out,
                           void* stream);
 
+/* Everything ManagerBasedRLEnv.step does after its last physics sub-step, for a height-scan locomotion task, as ONE
+ * launch (manager_based_rl_env.py:195-238 without the reset branch):
+ *   scene.update(physics_dt)                                  -> mdp_scene_update          (update, may be NULL)
+ *   episode_length_buf += 1; terminations; rewards            -> mdp_termination_reward_compute
+ *   command_manager.compute(step_dt)                          -> mdp_velocity_command_compute (command, may be NULL)
+ *   observation_manager.compute() incl. the lazy ray cast     -> mdp_obs_compute + mdp_raycaster_update (+ scan)
+ * Every stage is independent per env, so a block of the launch owns 64 envs and walks them through the stages in the
+ * reference order (block barriers in between), while other blocks of the same launch cast the height-scan rays (the cast
+ * only needs the physics transforms: pose_xyzw + tick_dt as in mdp_raycaster_update).  Outputs are bit-identical to the
+ * separate calls.  Restrictions (MDP_ERR_UNSUPPORTED otherwise; callers fall back to the separate calls): the cast must
+ * qualify for the vertical-ray kernel (yaw-only attachment, pattern_vertical_down, grid-accelerated mesh), a single
+ * command term, no lazily evaluated sensor read by a termination / reward term.  The structs only bundle the arguments
+ * of the calls named above. */
+typedef struct {
+    mdp_program_t* termination;
+    mdp_program_t* reward;
+    float dt;
+    int32_t pad0;
+    int64_t* episode_length_buf_inc;
+    uint8_t* term_dones;
+    uint8_t* truncated;
+    uint8_t* terminated;
+    uint8_t* dones;
+    float* reward_buf;
+    float* episode_sums;
+    float* step_reward;
+} mdp_termination_reward_args_t;
+
+typedef struct {
+    mdp_velocity_command_cfg_t cfg;
+    int32_t ld_state;
+    const float* root_state;
+    float* vel_command_b;
+    float* heading_target;
+    uint8_t* is_heading_env;
+    uint8_t* is_standing_env;
+    float* time_left;
+    int64_t* command_counter;
+    float* metric_error_vel_xy;
+    float* metric_error_vel_yaw;
+    float dt;
+    int32_t pad0;
+    uint64_t* rng_state;      /* {seed, -, -, -, one epoch counter per manager block ...}: 4 + N words */
+    const float* injected_u;
+} mdp_velocity_command_args_t;
+
+typedef struct {
+    mdp_program_t* program;
+    float* obs;
+    int32_t ld_obs;
+    int32_t pad0;
+} mdp_obs_args_t;
+
+typedef struct {
+    const mdp_mesh_t* mesh;
+    int32_t num_rays, ld_pose, pose_xyzw, attach_yaw_only, pattern_vertical_down, pad0;
+    const float* root_pose;
+    const float* drift;
+    const float* ray_starts_local;
+    const float* ray_dirs_local;
+    float max_dist, tick_dt, update_period, pad1;
+    float* pos_w;
+    float* quat_w;
+    float* ray_hits_w;
+    float* timestamp;
+    float* timestamp_last_update;
+    uint8_t* is_outdated;
+    const struct mdp_height_scan_obs* scan;
+} mdp_raycaster_update_args_t;
+
+int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                          const mdp_termination_reward_args_t* termination_reward,
+                          const mdp_velocity_command_args_t* command, const mdp_obs_args_t* observation,
+                          const mdp_raycaster_update_args_t* cast, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

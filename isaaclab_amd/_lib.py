@@ -82,6 +82,49 @@ class MdpVelocityCommandCfg(C.Structure):
     ]
 
 
+class MdpTerminationRewardArgs(C.Structure):
+    """Mirror of ``mdp_termination_reward_args_t``."""
+
+    _fields_ = [
+        ("termination", C.c_void_p), ("reward", C.c_void_p), ("dt", C.c_float), ("pad0", C.c_int32),
+        ("episode_length_buf_inc", C.c_void_p), ("term_dones", C.c_void_p), ("truncated", C.c_void_p),
+        ("terminated", C.c_void_p), ("dones", C.c_void_p), ("reward_buf", C.c_void_p),
+        ("episode_sums", C.c_void_p), ("step_reward", C.c_void_p),
+    ]
+
+
+class MdpVelocityCommandArgs(C.Structure):
+    """Mirror of ``mdp_velocity_command_args_t``."""
+
+    _fields_ = [
+        ("cfg", MdpVelocityCommandCfg), ("ld_state", C.c_int32), ("root_state", C.c_void_p),
+        ("vel_command_b", C.c_void_p), ("heading_target", C.c_void_p), ("is_heading_env", C.c_void_p),
+        ("is_standing_env", C.c_void_p), ("time_left", C.c_void_p), ("command_counter", C.c_void_p),
+        ("metric_error_vel_xy", C.c_void_p), ("metric_error_vel_yaw", C.c_void_p), ("dt", C.c_float),
+        ("pad0", C.c_int32), ("rng_state", C.c_void_p), ("injected_u", C.c_void_p),
+    ]
+
+
+class MdpObsArgs(C.Structure):
+    """Mirror of ``mdp_obs_args_t``."""
+
+    _fields_ = [("program", C.c_void_p), ("obs", C.c_void_p), ("ld_obs", C.c_int32), ("pad0", C.c_int32)]
+
+
+class MdpRaycasterUpdateArgs(C.Structure):
+    """Mirror of ``mdp_raycaster_update_args_t``."""
+
+    _fields_ = [
+        ("mesh", C.c_void_p), ("num_rays", C.c_int32), ("ld_pose", C.c_int32), ("pose_xyzw", C.c_int32),
+        ("attach_yaw_only", C.c_int32), ("pattern_vertical_down", C.c_int32), ("pad0", C.c_int32),
+        ("root_pose", C.c_void_p), ("drift", C.c_void_p), ("ray_starts_local", C.c_void_p),
+        ("ray_dirs_local", C.c_void_p), ("max_dist", C.c_float), ("tick_dt", C.c_float),
+        ("update_period", C.c_float), ("pad1", C.c_float), ("pos_w", C.c_void_p), ("quat_w", C.c_void_p),
+        ("ray_hits_w", C.c_void_p), ("timestamp", C.c_void_p), ("timestamp_last_update", C.c_void_p),
+        ("is_outdated", C.c_void_p), ("scan", C.c_void_p),
+    ]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -13,6 +13,9 @@
 #include "mesh_handle.hpp"
 #include "term_ops.h"
 #include "obs_post_device.hpp"
+#include "raycaster_update_device.hpp"
+#include "scene_update_device.hpp"
+#include "command_device.hpp"
 
 #include <cstdlib>
 #include <algorithm>
@@ -31,7 +34,8 @@ struct mdp_program {
     int32_t* d_pool = nullptr;
     RayAux* d_aux = nullptr;
     int16_t* d_col2term = nullptr;
-    uint64_t* d_rng = nullptr;  // {seed, per-block epoch counters}
+    uint64_t* d_rng = nullptr;  // {seed, per-block epoch counters of k_obs, per-64-env-block counters of k_post_physics}
+    unsigned rng_post_base = 0; // first k_post_physics counter
     int total_cols = 0;
     int active_cols = 0;  // columns up to the last one this program writes itself (trailing MDP_OBS_SKIP terms excluded)
     int uses_rng = 0;
@@ -648,6 +652,145 @@ __global__ void k_term_reward(const mdp_term_t* __restrict__ tterms, int Tt, con
     }
 }
 
+// =============================================================================================
+// Post-physics step in one launch (mdp_post_physics_step)
+// =============================================================================================
+constexpr int POST_ENVS_MAX = 64;  // envs per manager block: one wave lane per env in the term phases
+
+struct PostArgs {
+    int N;
+    // ---- manager role: blocks [0, nb_post), post_envs envs each.  They come first in the grid: a manager block is a
+    // chain of dependent phases (the long pole of the launch), so it has to be resident from the start
+    unsigned nb_post;
+    int post_envs;
+    // ---- cast role: the remaining blocks
+    unsigned nb_cast;
+    int cast_epb, cast_slot_w;
+    RaycasterUpdateArgs cast;
+    int has_upd;
+    float physics_dt;
+    mdp_scene_update_t upd;
+    const mdp_term_t* tterms; int Tt; const int32_t* tpool;
+    const mdp_term_t* rterms; int Tr; const int32_t* rpool;
+    float step_dt;
+    int64_t* len_inc;
+    uint8_t* term_dones; uint8_t* truncated; uint8_t* terminated; uint8_t* dones;
+    float* reward; float* sums; float* step;
+    int has_cmd;
+    mdp_velocity_command_args_t cmd;
+    const mdp_term_t* oterms; int To; const int32_t* opool; const int16_t* col2term; int O;
+    float* obs; int ld_obs; uint64_t* orng; unsigned orng_base; int ouses_rng;
+};
+
+template <int BATCH>
+__global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
+    extern __shared__ __align__(16) unsigned char s_dyn[];
+    if (blockIdx.x >= a.nb_post) {
+        raycaster_update_down_blocks<BATCH>(a.cast, a.cast_epb, a.cast_slot_w, blockIdx.x - a.nb_post, a.nb_cast);
+        return;
+    }
+    const unsigned b = blockIdx.x;
+    const int N = a.N;
+    const int E = a.post_envs;
+    const int e0 = (int)b * E;
+    const int e1 = e0 + E < N ? e0 + E : N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int tmax = a.Tt > a.Tr ? a.Tt : a.Tr;
+    float* s_val = reinterpret_cast<float*>(s_dyn);                                   // [tmax][64]
+    mdp_term_t* oterms = reinterpret_cast<mdp_term_t*>(s_dyn + (size_t)(tmax > 0 ? tmax : 1) * 64 * sizeof(float));
+    int16_t* col2term = reinterpret_cast<int16_t*>(reinterpret_cast<unsigned char*>(oterms) + (size_t)a.To * sizeof(mdp_term_t));
+    // observation term table -> LDS (independent of everything below; first use is after several barriers)
+    if (a.obs) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.oterms);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(oterms);
+        const int words = a.To * (int)(sizeof(mdp_term_t) / 4);
+        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < a.O; i += blockDim.x) col2term[i] = a.col2term[i];
+    }
+    // ---- scene.update(physics_dt) for this block's envs (interactive_scene.py:496-513)
+    if (a.has_upd) scene_update_envs(a.upd, a.physics_dt, e0, e1);
+    const int e = lane < E ? e0 + lane : N;   // lanes beyond the block's envs idle through the term phases
+    // ---- episode_length_buf += 1 (manager_based_rl_env.py:199)
+    if (a.len_inc && wave == 0 && e < N) a.len_inc[e] += 1;
+    __threadfence_block();
+    __syncthreads();
+    // ---- terminations (termination_manager.py:151-174): wave w evaluates terms w, w + nwaves, ...
+    for (int ti = wave; ti < a.Tt; ti += nwaves) {
+        const mdp_term_t& t = a.tterms[ti];
+        bool v = e < N ? term_value(t, a.tpool, e) : false;
+        if (a.term_dones && e < N) a.term_dones[(int64_t)t.out_offset * N + e] = v ? 1 : 0;
+        s_val[ti * 64 + lane] = v ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    if (wave == 0 && e < N && a.Tt > 0) {
+        bool trunc = false, term = false;
+        for (int ti = 0; ti < a.Tt; ++ti) {
+            bool v = s_val[ti * 64 + lane] != 0.0f;
+            if (a.tterms[ti].i3) trunc = trunc || v; else term = term || v;
+        }
+        if (a.truncated) a.truncated[e] = trunc ? 1 : 0;
+        if (a.terminated) a.terminated[e] = term ? 1 : 0;
+        if (a.dones) a.dones[e] = (trunc || term) ? 1 : 0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- rewards (reward_manager.py:128-157)
+    for (int ti = wave; ti < a.Tr; ti += nwaves) {
+        const mdp_term_t& t = a.rterms[ti];
+        float value = 0.0f;
+        if (e < N && t.weight != 0.0f) {
+            value = reward_value(t, a.rpool, e, N) * t.weight * a.step_dt;
+            if (a.sums) a.sums[(int64_t)t.out_offset * N + e] += value;
+            if (a.step) a.step[(int64_t)e * a.Tr + t.out_offset] = value / a.step_dt;
+        }
+        s_val[ti * 64 + lane] = value;
+    }
+    __syncthreads();
+    if (wave == 0 && e < N && a.Tr > 0) {
+        float total = 0.0f;
+        for (int ti = 0; ti < a.Tr; ++ti)
+            if (a.rterms[ti].weight != 0.0f) total += s_val[ti * 64 + lane];
+        a.reward[e] = total;
+    }
+    // ---- command_manager.compute(step_dt) (command_manager.py:151-187, velocity_command.py:111-160): after the
+    // rewards, which read the previous command
+    __syncthreads();
+    if (a.has_cmd) {
+        uint64_t seed = 0, epoch = 0;
+        const bool gen = a.cmd.rng_state != nullptr && a.cmd.injected_u == nullptr;
+        if (a.cmd.rng_state) { seed = a.cmd.rng_state[0]; epoch = a.cmd.rng_state[4 + b]; }
+        if (wave == 0 && e < N)
+            velocity_command_env(a.cmd.cfg, e, a.cmd.root_state, a.cmd.ld_state, a.cmd.vel_command_b, a.cmd.heading_target,
+                                 a.cmd.is_heading_env, a.cmd.is_standing_env, a.cmd.time_left, a.cmd.command_counter,
+                                 a.cmd.metric_error_vel_xy, a.cmd.metric_error_vel_yaw, a.cmd.dt, seed, epoch | (1ull << 62),
+                                 a.cmd.injected_u, nullptr);
+        if (gen && threadIdx.x == 0) a.cmd.rng_state[4 + b] = epoch + 1;
+        __threadfence_block();
+        __syncthreads();
+    }
+    // ---- observations (observation_manager.py:260-335), columns fastest: contiguous row writes
+    if (a.obs) {
+        uint64_t seed = 0, epoch = 0;
+        // own counters, tagged so that a draw never repeats one made by k_obs for the same element
+        if (a.ouses_rng) { seed = a.orng[0]; epoch = a.orng[a.orng_base + b]; }
+        const int O = a.O;
+        const int total = (e1 - e0) * O;
+        for (int i = threadIdx.x; i < total; i += blockDim.x) {
+            int le = i / O;
+            int c = i - le * O;
+            int ee = e0 + le;
+            int ti = col2term[c];
+            const mdp_term_t& t = oterms[ti];
+            if (t.op == MDP_OBS_SKIP || t.op == MDP_OBS_HEIGHT_SCAN_CAST) continue;
+            int k = c - t.out_offset;
+            float v = obs_value(t, a.opool, ee, k);
+            v = obs_post(t, v, ee, k, seed, epoch | (1ull << 62), 0x4f425300u + (uint32_t)ti, (uint64_t)ee * (uint64_t)O + c);
+            a.obs[(int64_t)ee * a.ld_obs + c] = v;
+        }
+        if (a.ouses_rng && threadIdx.x == 0) a.orng[a.orng_base + b] = epoch + 1;
+    }
+}
+
 // ---- single-term evaluation: the term travels as a kernel argument (no allocation, no sync) ----
 __global__ void k_obs_single(mdp_term_t t, const int32_t* __restrict__ pool, int N, float* __restrict__ out, int ld,
                              uint64_t seed, uint64_t epoch) {
@@ -757,7 +900,8 @@ extern "C" int mdp_program_create(int kind, int device, int num_envs, const mdp_
     }
     {
         // {seed, epoch of block 0, epoch of block 1, ...}: one counter per block of the observation grid
-        std::vector<uint64_t> rng((size_t)1 + std::max(obs_grid(p->num_envs, p->total_cols), obs_grid(p->num_envs, p->active_cols)), 0);
+        p->rng_post_base = 1 + std::max(obs_grid(p->num_envs, p->total_cols), obs_grid(p->num_envs, p->active_cols));
+        std::vector<uint64_t> rng((size_t)p->rng_post_base + (size_t)p->num_envs + 1, 0);  // post_envs >= 1
         rng[0] = seed;
         MDP_CHECK_HIP(dmalloc((void**)&p->d_rng, sizeof(uint64_t) * rng.size()));
         MDP_CHECK_HIP(hipMemcpy(p->d_rng, rng.data(), sizeof(uint64_t) * rng.size(), hipMemcpyHostToDevice));
@@ -845,6 +989,109 @@ extern "C" int mdp_termination_reward_compute(mdp_program_t* tp, mdp_program_t* 
                        as_stream(stream), tp->d_terms, tp->num_terms, tp->d_pool, rp->d_terms, rp->num_terms, rp->d_pool,
                        tp->num_envs, dt, episode_length_buf_inc, term_dones, truncated, terminated, dones, reward_buf,
                        episode_sums, step_reward);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                     const mdp_termination_reward_args_t* tr, const mdp_velocity_command_args_t* command,
+                                     const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
+                                     void* stream) {
+    MDP_REQUIRE(num_envs >= 0, "negative num_envs");
+    MDP_REQUIRE(tr && tr->termination && tr->reward, "termination / reward programs required");
+    mdp_program_t* tp = tr->termination;
+    mdp_program_t* rp = tr->reward;
+    MDP_REQUIRE(tp->kind == MDP_PROG_TERMINATION && rp->kind == MDP_PROG_REWARD, "wrong program kinds");
+    MDP_REQUIRE(tp->num_envs == num_envs && rp->num_envs == num_envs, "programs disagree on num_envs");
+    MDP_REQUIRE(tr->reward_buf || rp->num_terms == 0, "null reward buffer");
+    if (num_envs == 0) return MDP_OK;
+    PostArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.N = num_envs;
+    static const int threads_env = [] {
+        const char* v = std::getenv("MDP_POST_THREADS");
+        int t = v ? std::atoi(v) : 0;      // 0: whole waves covering one cast slot group (<= 256 threads)
+        return t <= 0 ? 0 : (t < 64 ? 64 : (t > 1024 ? 1024 : (t / 64) * 64));
+    }();
+    static const int post_envs = [] {
+        const char* v = std::getenv("MDP_POST_ENVS");
+        int e = v ? std::atoi(v) : 16;     // measured best on MI355X at 4096 envs
+        return e < 1 ? 1 : (e > POST_ENVS_MAX ? POST_ENVS_MAX : e);
+    }();
+    int threads = threads_env > 0 ? threads_env : 256;
+    if (threads_env <= 0 && cast && cast->num_rays > 0 && cast->num_rays < 256)
+        threads = (((256 / cast->num_rays) * cast->num_rays + 63) / 64) * 64;   // 187 rays -> 192 threads
+    // ---- cast
+    if (cast) {
+        MDP_REQUIRE(cast->mesh && cast->root_pose && cast->ray_starts_local && cast->ray_dirs_local && cast->pos_w &&
+                        cast->quat_w && cast->ray_hits_w && cast->num_rays > 0, "cast: null pointer");
+        MDP_REQUIRE(cast->ld_pose >= 7, "cast: root_pose must be (N,>=7)");
+        MDP_REQUIRE(!(cast->tick_dt > 0.0f) || (cast->timestamp && cast->timestamp_last_update && cast->is_outdated),
+                    "cast: tick_dt needs the bookkeeping buffers");
+        if (!(cast->pattern_vertical_down && cast->attach_yaw_only && cast->mesh->view.accel == 1 && cast->mesh->view.cell_recs))
+            return fail(MDP_ERR_UNSUPPORTED, "post-physics launch needs a cast that qualifies for the vertical-ray kernel");
+        RaycasterUpdateArgs& ra = a.cast;
+        ra.mesh = cast->mesh->view; ra.N = num_envs; ra.R = cast->num_rays; ra.pose = cast->root_pose;
+        ra.ld_pose = cast->ld_pose; ra.pose_xyzw = cast->pose_xyzw; ra.drift = cast->drift;
+        ra.starts_l = cast->ray_starts_local; ra.dirs_l = cast->ray_dirs_local; ra.max_dist = cast->max_dist;
+        ra.pos_w = cast->pos_w; ra.quat_w = cast->quat_w; ra.hits = cast->ray_hits_w; ra.ts = cast->timestamp;
+        ra.ts_last = cast->timestamp_last_update; ra.outdated = cast->is_outdated; ra.tick_dt = cast->tick_dt;
+        ra.period = cast->update_period;
+        if (cast->scan && cast->scan->obs) {
+            const mdp_height_scan_obs_t* sc = cast->scan;
+            MDP_REQUIRE(sc->ld_obs >= sc->col_offset + cast->num_rays && sc->col_offset >= 0, "height-scan columns do not fit");
+            const bool generated = (sc->post.noise_kind == 1 || sc->post.noise_kind == 2) && !sc->post.noise_u;
+            MDP_REQUIRE(!generated || sc->rng, "generated noise needs the rng words");
+            ra.scan = *sc;
+            if (!generated) ra.scan.rng = nullptr;
+        }
+        a.cast_epb = cast->num_rays >= threads ? 1 : threads / cast->num_rays;
+        a.cast_slot_w = cast->num_rays >= threads ? threads : cast->num_rays;
+        a.nb_cast = (unsigned)std::min<int64_t>(((int64_t)num_envs + a.cast_epb - 1) / a.cast_epb, 1 << 20);
+    }
+    // ---- scene update
+    if (update) {
+        SceneUpdatePlan plan;
+        int rc = scene_update_plan(update, &plan);
+        if (rc != MDP_OK) return rc;
+        MDP_REQUIRE(update->num_envs == num_envs, "scene update disagrees on num_envs");
+        a.upd = plan.d;
+        a.has_upd = 1;
+        a.physics_dt = physics_dt;
+    }
+    // ---- terminations / rewards
+    a.tterms = tp->d_terms; a.Tt = tp->num_terms; a.tpool = tp->d_pool;
+    a.rterms = rp->d_terms; a.Tr = rp->num_terms; a.rpool = rp->d_pool;
+    a.step_dt = tr->dt; a.len_inc = tr->episode_length_buf_inc;
+    a.term_dones = tr->term_dones; a.truncated = tr->truncated; a.terminated = tr->terminated; a.dones = tr->dones;
+    a.reward = tr->reward_buf; a.sums = tr->episode_sums; a.step = tr->step_reward;
+    // ---- command
+    if (command) {
+        MDP_REQUIRE(command->root_state && command->vel_command_b && command->heading_target && command->is_heading_env &&
+                        command->is_standing_env && command->time_left && command->command_counter &&
+                        command->metric_error_vel_xy && command->metric_error_vel_yaw, "command: null pointer");
+        MDP_REQUIRE(command->rng_state || command->injected_u, "command: need rng_state or injected_u");
+        MDP_REQUIRE(command->ld_state >= 13, "command: root_state must be (N,13)");
+        a.cmd = *command;
+        a.has_cmd = 1;
+    }
+    // ---- observations
+    size_t lds = (size_t)((a.Tt > a.Tr ? a.Tt : a.Tr) > 0 ? (a.Tt > a.Tr ? a.Tt : a.Tr) : 1) * 64 * sizeof(float);
+    if (observation && observation->program) {
+        mdp_program_t* op = observation->program;
+        MDP_REQUIRE(op->kind == MDP_PROG_OBS && op->num_envs == num_envs, "not an observation program of this size");
+        MDP_REQUIRE(observation->obs && observation->ld_obs >= op->total_cols, "obs buffer too narrow");
+        if (op->active_cols > 0) {
+            a.oterms = op->d_terms; a.To = op->num_terms; a.opool = op->d_pool; a.col2term = op->d_col2term;
+            a.O = op->active_cols; a.obs = observation->obs; a.ld_obs = observation->ld_obs; a.orng = op->d_rng; a.orng_base = op->rng_post_base;
+            a.ouses_rng = op->uses_rng;
+            lds += (size_t)op->num_terms * sizeof(mdp_term_t) + (size_t)a.O * sizeof(int16_t) + 16;
+        }
+    }
+    if (lds > 60 * 1024) return fail(MDP_ERR_UNSUPPORTED, "programs too large for the LDS staging area (%zu B)", lds);
+    a.post_envs = post_envs;
+    a.nb_post = (unsigned)(((int64_t)num_envs + post_envs - 1) / post_envs);
+    hipLaunchKernelGGL(k_post_physics<2>, dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -6,6 +6,7 @@
 #include "raycast_device.hpp"
 #include "mesh_handle.hpp"
 #include "obs_post_device.hpp"
+#include "raycaster_update_device.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -381,14 +382,6 @@ __device__ __forceinline__ mdp_hit_t rc_query(const mdp_mesh_view_t* m, const md
     return mdp_rc_brute(m, r, max_t);
 }
 
-// height_scan observation column of ray r of env e, written by the cast kernels (mdp_height_scan_obs_t)
-__device__ __forceinline__ void scan_store(const mdp_height_scan_obs_t& sc, int e, int r, int R, float sensor_z, float hit_z,
-                                           uint64_t seed, uint64_t epoch) {
-    float v = (sensor_z - hit_z) - sc.offset;   // observations.py:173
-    v = obs_post(sc.post, v, e, r, seed, epoch, 0x48534341u, (uint64_t)e * (uint64_t)R + (uint64_t)r);
-    sc.obs[(int64_t)e * sc.ld_obs + sc.col_offset + r] = v;
-}
-
 // ops.py:61-127 + kernels.py:55-75: one thread per ray
 template <int ACCEL>
 __global__ void k_raycast(mdp_mesh_view_t mesh, int64_t num_rays, const float* __restrict__ starts,
@@ -493,73 +486,11 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
     if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + blockIdx.x] = epoch + 1;
 }
 
-// The height-scan case of k_raycaster_update: yaw-only attachment and a pattern whose directions are all (0, 0, -c),
-// on a mesh with cell records.  One env per 192/256-thread slot as above; the sensor pose is rotated once per env by
-// its first lanes and shared through LDS.
+// The height-scan case of k_raycaster_update (body in raycaster_update_device.hpp, shared with the post-physics kernel)
 template <int BATCH>
 __global__ void __launch_bounds__(256)
-k_raycaster_update_down(mdp_mesh_view_t mesh, int N, int R, int epb, int slot_w, const float* __restrict__ pose,
-                        int ld_pose, const float* __restrict__ drift, const float* __restrict__ starts_l,
-                        const float* __restrict__ dirs_l, float max_dist, float* __restrict__ pos_w,
-                        float* __restrict__ quat_w, float* __restrict__ hits, float* __restrict__ ts,
-                        float* __restrict__ ts_last, uint8_t* __restrict__ outdated, mdp_height_scan_obs_t scan,
-                        int pose_xyzw, float tick_dt, float period) {
-    const float inf = __builtin_inff();
-    int le = threadIdx.x / slot_w;
-    int lr = threadIdx.x - le * slot_w;
-    uint64_t seed = 0, epoch = 0;
-    if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + blockIdx.x]; }
-    for (int base = blockIdx.x * epb; base < N; base += gridDim.x * epb) {
-        int e = base + le;
-        bool active = le < epb && e < N;
-        if (tick_dt > 0.0f) {
-            // SensorBase.update of this physics step (sensor_base.py:197-205) done here, so the cast does not have
-            // to wait for the launch that updates the rest of the scene
-            if (active && lr == 0) {
-                float t = ts[e] + tick_dt;
-                ts[e] = t;
-                if ((t - ts_last[e]) + 1e-6f >= period) outdated[e] = 1;
-            }
-            __syncthreads();
-        }
-        bool od = active && (outdated ? outdated[e] != 0 : true);
-        __syncthreads();
-        if (active && !od && scan.obs) {
-            float sz = pos_w[3 * (int64_t)e + 2];
-            for (int r = lr; r < R; r += slot_w) scan_store(scan, e, r, R, sz, hits[((int64_t)e * R + r) * 3 + 2], seed, epoch);
-        }
-        if (od) {
-            const float* p = pose + (int64_t)e * ld_pose;
-            V3 pos = ld3(p);
-            if (drift) { pos.x += drift[3 * e]; pos.y += drift[3 * e + 1]; pos.z += drift[3 * e + 2]; }
-            // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows are (w, x, y, z)
-            Q4 q = pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
-            Q4 qr = yaw_quat(q);
-            for (int r = lr; r < R; r += slot_w) {
-                V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
-                s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
-                V3 d = ld3(dirs_l + 3 * r);
-                mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
-                mdp_hit_t h = mdp_rc_grid_down<BATCH>(&mesh, &ray, max_dist);
-                float* o = hits + ((int64_t)e * R + r) * 3;
-                float hz = inf;
-                if (h.face >= 0) {
-                    hz = s.z + h.t * d.z;
-                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = hz;
-                } else {
-                    o[0] = inf; o[1] = inf; o[2] = inf;
-                }
-                if (scan.obs) scan_store(scan, e, r, R, pos.z, hz, seed, epoch);
-            }
-            if (lr == 0) {
-                st3(pos_w + 3 * (int64_t)e, pos);
-                st4(quat_w + 4 * (int64_t)e, q);
-                if (ts_last) ts_last[e] = ts[e];
-                if (outdated) outdated[e] = 0;
-            }
-        }
-    }
-    if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + blockIdx.x] = epoch + 1;
+k_raycaster_update_down(RaycasterUpdateArgs a, int epb, int slot_w) {
+    raycaster_update_down_blocks<BATCH>(a, epb, slot_w, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -612,11 +543,15 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     }
     if (pattern_vertical_down && attach_yaw_only && mesh->view.accel == 1 && mesh->view.cell_recs) {
         static const int batch = [] { const char* b = std::getenv("MDP_RC_BATCH"); return b ? std::atoi(b) : 2; }();
+        RaycasterUpdateArgs ra;
+        ra.mesh = mesh->view; ra.N = num_envs; ra.R = num_rays; ra.pose = root_pose; ra.ld_pose = ld_pose;
+        ra.pose_xyzw = pose_xyzw; ra.drift = drift; ra.starts_l = ray_starts_local; ra.dirs_l = ray_dirs_local;
+        ra.max_dist = max_dist; ra.pos_w = pos_w; ra.quat_w = quat_w; ra.hits = ray_hits_w; ra.ts = timestamp;
+        ra.ts_last = timestamp_last_update; ra.outdated = is_outdated; ra.scan = sc; ra.tick_dt = tick_dt;
+        ra.period = update_period;
 #define RCD_LAUNCH(B)                                                                                             \
     hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,          \
-                       as_stream(stream), mesh->view, num_envs, num_rays, epb, slot_w, root_pose, ld_pose, drift,  \
-                       ray_starts_local, ray_dirs_local, max_dist, pos_w, quat_w, ray_hits_w, timestamp,           \
-                       timestamp_last_update, is_outdated, sc, pose_xyzw, tick_dt, update_period)
+                       as_stream(stream), ra, epb, slot_w)
         if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
 #undef RCD_LAUNCH
         MDP_LAUNCH_CHECK();

@@ -121,6 +121,78 @@ __device__ __forceinline__ void scene_update_block(const mdp_scene_update_t& d, 
     }
 }
 
+// The same update restricted to the envs [e0, e1), executed by ONE whole block (any blockDim.x): used by the
+// post-physics kernel, whose blocks each own a range of envs for every stage of the step.  Every thread of the block
+// must call it (it contains a barrier).
+__device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, float dt, int e0, int e1) {
+    const int n = e1 - e0;
+    if (d.root_state_w) {
+        for (int i = threadIdx.x; i < n * 13; i += blockDim.x) {
+            int64_t r = e0 + i / 13;
+            int k = i % 13;
+            float v;
+            if (k < 3) v = d.root_transforms[7 * r + k];
+            else if (k == 3) v = d.root_transforms[7 * r + 6];
+            else if (k < 7) v = d.root_transforms[7 * r + k - 1];
+            else v = d.root_velocities[6 * r + (k - 7)];
+            d.root_state_w[13 * r + k] = v;
+        }
+    }
+    if (d.joint_vel_src && d.num_joints > 0) {
+        const int J = d.num_joints;
+        for (int i = threadIdx.x; i < n * J; i += blockDim.x) {
+            int64_t e = e0 + i / J;
+            int j = i % J;
+            int64_t o = e * J + j;
+            float qd = d.joint_vel_src[e * d.ld_joint_src + j];
+            if (d.joint_vel) d.joint_vel[o] = qd;
+            if (d.joint_pos) d.joint_pos[o] = d.joint_pos_src[e * d.ld_joint_src + j];
+            if (d.joint_acc) {
+                d.joint_acc[o] = (qd - d.prev_joint_vel[o]) / d.acc_elapsed;
+                d.prev_joint_vel[o] = qd;
+            }
+        }
+    }
+    const bool has_contact = d.net_contact_forces != nullptr && d.num_contact_bodies > 0;
+    if (has_contact) {
+        const int B = d.num_contact_bodies;
+        for (int i = threadIdx.x; i < n * B; i += blockDim.x) {
+            int e = e0 + i / B;
+            int bb = i % B;
+            float t_new = d.contact_timestamp[e] + dt;
+            float t_last = d.contact_timestamp_last_update[e];
+            bool od = (d.contact_is_outdated[e] != 0) || ((t_new - t_last) + 1e-6f >= d.contact_update_period);
+            if (od && d.contact_eager)
+                contact_body_update((int64_t)e * B + bb, e, bb, B, d.history_len, d.net_contact_forces, d.net_forces_w,
+                                    d.net_forces_w_history, d.last_air_time, d.current_air_time, d.last_contact_time,
+                                    d.current_contact_time, t_new - t_last, d.force_threshold);
+        }
+    }
+    __syncthreads();  // every body thread has read the env's bookkeeping words before they are committed
+    if (has_contact) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            int e = e0 + i;
+            float t_new = d.contact_timestamp[e] + dt;
+            float t_last = d.contact_timestamp_last_update[e];
+            bool od = (d.contact_is_outdated[e] != 0) || ((t_new - t_last) + 1e-6f >= d.contact_update_period);
+            d.contact_timestamp[e] = t_new;
+            if (od && d.contact_eager) {
+                d.contact_timestamp_last_update[e] = t_new;
+                od = false;
+            }
+            d.contact_is_outdated[e] = od ? 1 : 0;
+        }
+    }
+    for (int s = 0; s < d.num_ticks; ++s) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            int e = e0 + i;
+            float t = d.tick_timestamp[s][e] + dt;
+            d.tick_timestamp[s][e] = t;
+            if ((t - d.tick_timestamp_last_update[s][e]) + 1e-6f >= d.tick_update_period[s]) d.tick_is_outdated[s][e] = 1;
+        }
+    }
+}
+
 struct SceneUpdatePlan {
     mdp_scene_update_t d;
     unsigned nb_root = 0, nb_joint = 0, nb_contact = 0, nb_tick = 0, total = 0;

@@ -32,6 +32,8 @@ class ManagerBasedRLEnv:
         self.auto_reset = auto_reset
         self.fuse_post_physics = True   # episode counter + terminations + rewards in one launch
         self.fuse_substeps = True       # scene.update(k) + write_data_to_sim(k+1) in one launch
+        # last scene.update + terminations + rewards + command + observations + height-scan cast in one launch
+        self.single_launch_post_physics = True
         # (terminations + rewards, command) and the height-scan cast on two streams (only without a reset in between)
         self.concurrent_post_physics = torch.device(device).type == "cuda"
         if self.concurrent_post_physics:
@@ -119,8 +121,11 @@ class ManagerBasedRLEnv:
                     self.scene.write_data_to_sim()
             elif not early_cast:
                 self.scene.update(dt=self.physics_dt)
+            # (with early_cast the last scene.update runs after the loop, next to or inside the post-physics launches)
         self.common_step_counter += 1
-        if concurrent:
+        if early_cast and self.single_launch_post_physics and self._post_physics_single_launch():
+            pass
+        elif concurrent:
             # Without the reset path between them (manager_based_rl_env.py:214-229) the chain terminations -> rewards ->
             # command update -> observations and the height-scan cast do not depend on each other: they go to two
             # streams (two branches of a captured hipGraph) and join at the end of the step.  The cast reads the sensor
@@ -180,6 +185,56 @@ class ManagerBasedRLEnv:
             if prog is not None and any(getattr(spec, "lazy_sensors", None) for spec in prog.specs):
                 return True
         return False
+
+    def _post_physics_single_launch(self) -> bool:
+        """manager_based_rl_env.py:195-238 (last ``scene.update``, episode counter, terminations, rewards, command,
+        observations incl. the height-scan cast) as ONE launch, ``mdp_post_physics_step``.  False when the task does not
+        have the shape that entry point covers; the caller then uses the separate launches."""
+        import ctypes as C
+
+        from .. import _lib as L
+
+        om, cm = self.observation_manager, self.command_manager
+        oa = om.post_physics_args()
+        if oa is None:
+            return False
+        obs_args, sensor, scan, oprog, group_name, out = oa
+        terms = list(cm._terms.values())
+        if len(terms) != 1 or not hasattr(terms[0], "fill_post_physics"):
+            return False
+        if not (sensor._pattern_vertical_down and sensor.cfg.attach_yaw_only and self._mesh_has_grid(sensor._mesh)):
+            return False
+        plan = self.scene._scene_update_desc(self.physics_dt, skip_ticks=(sensor,))
+        if plan is None:
+            return False
+        d, art = plan
+        art.data.commit_scene_update(self.physics_dt)   # the lazy buffers are fresh once the launch below has run
+        tm, rm = self.termination_manager, self.reward_manager
+        tp, rp = tm.prepare_launch(), rm.prepare_launch()
+        tr = L.MdpTerminationRewardArgs()
+        tr.termination, tr.reward, tr.dt = tp.handle, rp.handle, float(self.step_dt)
+        tr.episode_length_buf_inc = self.episode_length_buf.data_ptr()
+        tr.term_dones, tr.truncated = tm._term_dones_block.data_ptr(), tm._truncated_buf.data_ptr()
+        tr.terminated, tr.dones = tm._terminated_buf.data_ptr(), tm._dones_buf.data_ptr()
+        tr.reward_buf, tr.episode_sums = rm._reward_buf.data_ptr(), rm._episode_sums_block.data_ptr()
+        tr.step_reward = rm._step_reward.data_ptr()
+        ca = terms[0].fill_post_physics(self.step_dt)
+        cast = sensor.fill_post_physics(scan, self.physics_dt)
+        oprog.run_before()
+        L.check(L.lib.mdp_post_physics_step(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
+                                            C.byref(obs_args), C.byref(cast), L.stream(self.device)))
+        self.reset_buf = tm._dones_buf
+        self.reward_buf = rm._reward_buf
+        om._obs_buffer = {group_name: out}
+        self.obs_buf = om._obs_buffer
+        self._single_launch_steps = getattr(self, "_single_launch_steps", 0) + 1
+        return True
+
+    def _mesh_has_grid(self, mesh) -> bool:
+        cache = self.__dict__.setdefault("_mesh_grid_cache", {})
+        if id(mesh) not in cache:
+            cache[id(mesh)] = mesh.info().get("accel") == "grid"
+        return cache[id(mesh)]
 
     def _termination_reward_fused(self):
         """manager_based_rl_env.py:199-206: ``episode_length_buf += 1``, ``termination_manager.compute()`` and

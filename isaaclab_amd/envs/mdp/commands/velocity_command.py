@@ -32,8 +32,10 @@ class UniformVelocityCommand(CommandTerm):
         self.metrics["error_vel_xy"] = torch.zeros(self.num_envs, device=self.device)
         self.metrics["error_vel_yaw"] = torch.zeros(self.num_envs, device=self.device)
         seed = int(getattr(cfg, "seed", None) or (torch.initial_seed() & 0x7FFFFFFFFFFFFFFF))
-        # {seed, epoch, ticket, pad}: advanced by the kernel itself (hipGraph-replay safe)
-        self._rng_state = torch.tensor([seed, 0, 0, 0], dtype=torch.int64, device=self.device)
+        # {seed, epoch, ticket, pad, one epoch per manager block of mdp_post_physics_step (<= num_envs) ...}: advanced by the kernels
+        # themselves (hipGraph-replay safe)
+        self._rng_state = torch.zeros(4 + self.num_envs, dtype=torch.int64, device=self.device)
+        self._rng_state[0] = seed
         self._ccfg = self._make_cfg()
         self.injected_uniforms: torch.Tensor | None = None  # (N,7) test hook: replaces the generator
 
@@ -76,6 +78,28 @@ class UniformVelocityCommand(CommandTerm):
             self.metrics["error_vel_yaw"].data_ptr(), float(dt), self._rng_state.data_ptr(),
             L.ptr(inj) if inj is not None else None, L.ptr(force_mask) if force_mask is not None else None,
             L.stream(self.device)))
+
+    def fill_post_physics(self, dt: float) -> "L.MdpVelocityCommandArgs":
+        """The arguments of :meth:`compute` as the command member of ``mdp_post_physics_step``."""
+        a = L.MdpVelocityCommandArgs()
+        st = self.robot.data.root_state_w
+        a.cfg = self._ccfg
+        a.ld_state = st.stride(0)
+        a.root_state = st.data_ptr()
+        a.vel_command_b = self.vel_command_b.data_ptr()
+        a.heading_target = self.heading_target.data_ptr()
+        a.is_heading_env = self.is_heading_env.data_ptr()
+        a.is_standing_env = self.is_standing_env.data_ptr()
+        a.time_left = self.time_left.data_ptr()
+        a.command_counter = self.command_counter.data_ptr()
+        a.metric_error_vel_xy = self.metrics["error_vel_xy"].data_ptr()
+        a.metric_error_vel_yaw = self.metrics["error_vel_yaw"].data_ptr()
+        a.dt = float(dt)
+        a.rng_state = self._rng_state.data_ptr()
+        inj = self.injected_uniforms
+        a.injected_u = inj.data_ptr() if inj is not None else None
+        self._post_keep = (st, inj)
+        return a
 
     def compute(self, dt: float):
         self._launch(dt, None)

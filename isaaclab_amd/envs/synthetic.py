@@ -147,7 +147,8 @@ def _env_cfg(name: str, num_envs: int, network=None):
 
 
 def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: int = 8, seed: int = 0,
-                      small_terrain: bool = False, inject_random: bool = True, network=None, terrain=None):
+                      small_terrain: bool = False, inject_random: bool = True, network=None, terrain=None,
+                      mesh_accel: str = "auto"):
     """Builds a velocity-task env over a replayed synthetic physics feed.  Returns ``(env, recording)``.
 
     ``inject_random=True`` replaces the device generators of the command term and of the observation noise by
@@ -164,7 +165,12 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
         gen = TerrainGeneratorCfg(num_rows=2, num_cols=5) if small_terrain else TerrainGeneratorCfg()
         terrain = SyntheticTerrain(SyntheticTerrainCfg(terrain_generator=gen, max_init_terrain_level=1 if small_terrain else 5),
                                    num_envs)
-    env = ManagerBasedRLEnv(cfg, device=device, terrain=terrain if rough else None)
+    mesh = None
+    if rough and mesh_accel != "auto":     # tests: pin the acceleration structure (and with it the cast kernel)
+        from ..utils.warp import convert_to_warp_mesh
+
+        mesh = convert_to_warp_mesh(terrain.vertices, terrain.triangles, device, accel=mesh_accel)
+    env = ManagerBasedRLEnv(cfg, device=device, terrain=terrain if rough else None, mesh=mesh)
     view = env.physics
     robot = env.scene["robot"]
     rec = Recording()

@@ -243,6 +243,23 @@ class ObservationManager(ManagerBase):
                     out.append(sensor)
         return out
 
+    def post_physics_args(self):
+        """``(MdpObsArgs, sensor, scan)`` for ``mdp_post_physics_step``: one fused group with a persistent output whose
+        only sensor-owned columns are one height scan written by its cast kernel; ``None`` when the observations do not
+        have that shape."""
+        if len(self._group_obs_term_names) != 1 or not self.can_split_sensor_terms():
+            return None
+        group_name = next(iter(self._group_obs_term_names))
+        scans = self._scans.get(group_name, [])
+        if len(scans) != 1 or self._external[group_name]:
+            return None
+        prog, out = self._programs[group_name], self._out_buffers[group_name]
+        sensor, scan = scans[0]
+        scan.obs, scan.ld_obs = out.data_ptr(), out.shape[1]
+        a = L.MdpObsArgs()
+        a.program, a.obs, a.ld_obs = prog.handle, out.data_ptr(), out.shape[1]
+        return a, sensor, scan, prog, group_name, out
+
     def can_split_sensor_terms(self) -> bool:
         """Whether ``compute_sensor_terms()`` + ``compute(skip_sensor_terms=True)`` can replace ``compute()``: every
         group is fused, its program is built and its output buffer is persistent."""

@@ -164,6 +164,30 @@ class RayCaster(SensorBase):
             self._is_outdated.data_ptr(), C.byref(scan) if scan is not None else None, xyzw, float(tick_dt),
             float(self.cfg.update_period), L.stream()))
 
+    def fill_post_physics(self, scan, tick_dt: float) -> "L.MdpRaycasterUpdateArgs":
+        """The arguments of ``_update_outdated_buffers(scan, tick_dt, from_physics=True)`` as the cast member of
+        ``mdp_post_physics_step``."""
+        import ctypes as C
+
+        a = L.MdpRaycasterUpdateArgs()
+        pose = self._view.get_root_transforms()
+        a.mesh = self._mesh.handle
+        a.num_rays, a.ld_pose, a.pose_xyzw = self.num_rays, pose.stride(0), 1
+        a.attach_yaw_only = 1 if self.cfg.attach_yaw_only else 0
+        a.pattern_vertical_down = 1 if self._pattern_vertical_down else 0
+        a.root_pose = pose.data_ptr()
+        a.drift = self.drift.data_ptr()
+        a.ray_starts_local = self._ray_starts_local.data_ptr()
+        a.ray_dirs_local = self._ray_dirs_local.data_ptr()
+        a.max_dist, a.tick_dt, a.update_period = float(self.cfg.max_distance), float(tick_dt), float(self.cfg.update_period)
+        a.pos_w, a.quat_w = self._data.pos_w.data_ptr(), self._data.quat_w.data_ptr()
+        a.ray_hits_w = self._data.ray_hits_w.data_ptr()
+        a.timestamp, a.timestamp_last_update = self._timestamp.data_ptr(), self._timestamp_last_update.data_ptr()
+        a.is_outdated = self._is_outdated.data_ptr()
+        a.scan = C.cast(C.pointer(scan), C.c_void_p) if scan is not None else None
+        self._post_keep = (pose, scan)
+        return a
+
 
 @configclass
 class RayCasterCfg(SensorBaseCfg):

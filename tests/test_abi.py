@@ -45,7 +45,10 @@ def test_struct_mirrors_match_header():
     """The header is plain C (compiles with gcc -std=c99) and the ctypes mirrors have the same size."""
     pairs = [("mdp_term_t", L.MdpTerm), ("mdp_raycaster_desc_t", L.MdpRaycasterDesc),
              ("mdp_velocity_command_cfg_t", L.MdpVelocityCommandCfg), ("mdp_net_desc_t", L.MdpNetDesc),
-             ("mdp_inhand_cfg_t", L.MdpInhandCfg), ("mdp_scene_update_t", L.MdpSceneUpdate), ("mdp_height_scan_obs_t", L.MdpHeightScanObs)]
+             ("mdp_inhand_cfg_t", L.MdpInhandCfg), ("mdp_scene_update_t", L.MdpSceneUpdate), ("mdp_height_scan_obs_t", L.MdpHeightScanObs),
+             ("mdp_termination_reward_args_t", L.MdpTerminationRewardArgs),
+             ("mdp_velocity_command_args_t", L.MdpVelocityCommandArgs), ("mdp_obs_args_t", L.MdpObsArgs),
+             ("mdp_raycaster_update_args_t", L.MdpRaycasterUpdateArgs)]
     sizes = _c_sizeof([p[0] for p in pairs])
     for (name, cls), sz in zip(pairs, sizes):
         assert C.sizeof(cls) == sz, f"{name}: header {sz} bytes, ctypes mirror {C.sizeof(cls)}"

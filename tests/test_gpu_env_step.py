@@ -10,7 +10,8 @@ from conftest import assert_close, to_np
 pytestmark = pytest.mark.gpu
 
 
-def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, persistent=False, scan_in_cast=None, **kw):
+def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, persistent=False, scan_in_cast=None,
+            single_launch=True, **kw):
     import torch
 
     from isaaclab_amd.envs.synthetic import make_velocity_env
@@ -22,6 +23,7 @@ def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, persistent
         env.scene.sensors["height_scanner"].scan_in_cast = scan_in_cast
     # persistent observation buffers let the step put the sensor-owned columns and the rest on two streams
     env.observation_manager.persistent_output = persistent
+    env.single_launch_post_physics = single_launch
     if not fused:      # the per-entity / per-manager launches of the reference call structure
         env.scene.fused_update = False
         env.fuse_post_physics = False
@@ -54,19 +56,28 @@ def test_anymal_d_flat(device, n):
     compare(outs, replay_oracle(rec, 6))
 
 
-@pytest.mark.parametrize("n,fuse_cast,fused,persistent,scan_in_cast",
-                         ((5, False, True, False, True), (128, False, True, True, True), (128, True, True, False, True),
-                          (37, False, False, False, True), (64, False, True, True, False)))
-def test_anymal_d_rough(device, n, fuse_cast, fused, persistent, scan_in_cast):
+@pytest.mark.parametrize("n,fuse_cast,fused,persistent,scan_in_cast,single_launch",
+                         ((5, False, True, False, True, True), (128, False, True, True, True, False),
+                          (128, True, True, False, True, True), (37, False, False, False, True, True),
+                          (64, False, True, True, False, True), (128, False, True, True, True, True),
+                          (203, False, True, True, True, True)))
+def test_anymal_d_rough(device, n, fuse_cast, fused, persistent, scan_in_cast, single_launch):
     """BASELINE config C2 (rough, 187-ray height scan, 235-dim observation): the default launch structure (fused
     scene update, fused termination + reward, vertical-ray cast kernel + lean observation kernel), the height scan
     cast inside the observation kernel, the unfused per-entity / per-manager launches, persistent observation buffers
-    (two-stream split of the observation) and the height scan read back from the sensor buffers."""
+    (two-stream split of the observation), the height scan read back from the sensor buffers, and everything after
+    the last physics sub-step as one launch (mdp_post_physics_step; 203 envs: ragged last 64-env block)."""
     from oracle.harness import replay_oracle
 
+    # the small terrain's flat border triangles make "auto" pick the BVH; the grid (what the full-size terrain gets)
+    # is what the vertical-ray kernel and the single post-physics launch need
+    accel = "grid" if (persistent and scan_in_cast and fused) or n == 5 else "auto"
     env, rec, outs = run_env("anymal_d_rough", n, 6, device, seed=12, small_terrain=True, fuse_cast=fuse_cast, fused=fused,
-                              persistent=persistent, scan_in_cast=scan_in_cast)
+                              persistent=persistent, scan_in_cast=scan_in_cast, single_launch=single_launch,
+                              mesh_accel=accel)
     assert outs[0][0].shape == (n, 235)
+    if persistent and scan_in_cast and fused:
+        assert getattr(env, "_single_launch_steps", 0) == (5 if single_launch else 0)
     compare(outs, replay_oracle(rec, 6))
     # sensor state after the run.  The rays themselves come from quat_apply_yaw on device vs host libm (1-ulp
     # differences in the ray origins), so hits agree to fp32 tolerance here; bit-exactness of the caster on
