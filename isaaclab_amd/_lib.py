@@ -12,7 +12,8 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libmdp_hip.so")
+# MDP_HIP_LIB: diagnostic builds only (e.g. the in-kernel stamp build of tools/kernel_stamps.py)
+LIB_PATH = os.environ.get("MDP_HIP_LIB") or os.path.join(_HERE, "_lib", "libmdp_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

@@ -14,6 +14,7 @@
 // (SURVEY.md section 8d); the MFMA pipe is there to keep the VALU free for the gate transcendentals.
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
+#include "stamps_device.hpp"
 #include "scene_update_device.hpp"
 
 #include <cstdlib>
@@ -184,13 +185,17 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
        float* __restrict__ computed, float* __restrict__ applied) {
     constexpr int TPL = H / 4;
     extern __shared__ __align__(16) float lds[];
-    if (blockIdx.x >= nb_act) {
-        scene_update_block(upd, dt, blockIdx.x - nb_act, nb_root, nb_joint, nb_contact);
+    // the carried scene update takes the FIRST blocks of the grid: its chain of dependent loads starts with the launch
+    // instead of behind the actuator blocks
+    const unsigned nb_upd = gridDim.x - nb_act;
+    if (blockIdx.x < nb_upd) {
+        scene_update_block(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact);
         return;
     }
+    const unsigned bid = blockIdx.x - nb_upd;
     int lane = threadIdx.x & 63;
     int gq = lane >> 4, col = lane & 15;
-    int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t wave = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int64_t nwaves = (int64_t)nb_act * (blockDim.x >> 6);
     int64_t ngroups = (rows + 15) / 16;
     // Software pipeline: the global loads of a group (inputs and the (h, c) slices of every layer) are issued before
@@ -304,13 +309,20 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
             const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
             float* __restrict__ computed, float* __restrict__ applied) {
     constexpr int H = 8, TPL = 2;
-    if (blockIdx.x >= nb_act) {
-        scene_update_block(upd, dt, blockIdx.x - nb_act, nb_root, nb_joint, nb_contact);
+    // the carried scene update takes the FIRST blocks of the grid: its chain of dependent loads starts with the launch
+    // instead of behind the actuator blocks
+    const unsigned nb_upd = gridDim.x - nb_act;
+    if (blockIdx.x < nb_upd) {
+        MDP_STAMP(0, 1);
+        scene_update_block(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact);
+        MDP_STAMP(1);
         return;
     }
+    MDP_STAMP(0, 2);
+    const unsigned bid = blockIdx.x - nb_upd;
     int lane = threadIdx.x & 63;
     int gq = lane >> 4, col = lane & 15;
-    int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    int64_t wave = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int64_t nwaves = (int64_t)nb_act * (blockDim.x >> 6);
     int64_t ngroups = (rows + 15) / 16;
     float x0 = 0.0f, x1 = 0.0f;
@@ -409,6 +421,7 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
         if (cvalid && gq == 0) dc_clip_store(tau, cx1, crr, eff_lim, vel_lim, sat, computed, applied);
         g = gnext;
     }
+    MDP_STAMP(1);
 }
 
 __global__ void __launch_bounds__(256)
@@ -561,6 +574,8 @@ static unsigned net_grid(int64_t rows) {
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
 }
+
+MDP_STAMP_SETTER(mdp_debug_stamps_actuator_nets)
 
 extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* update, float dt,
                                                       const mdp_net_desc_t* desc, const float* packed_weights,

@@ -10,7 +10,7 @@ namespace {
 
 // One thread per (env, joint) element, flat index -> perfectly coalesced on contiguous (N,J).
 // HBM-bound: reads q,qd,target(+gains), writes computed & applied.
-// Blocks >= nb_act carry the scene update of the frame this launch reads (scene.update(k) + write_data_to_sim(k+1) in one
+// The first gridDim.x - nb_act blocks carry the scene update of the frame this launch reads (scene.update(k) + write_data_to_sim(k+1) in one
 // launch; nb_act == gridDim.x when there is none).
 template <int KIND>
 __global__ void __launch_bounds__(256)
@@ -24,11 +24,12 @@ k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_roo
                               const float* __restrict__ kp, const float* __restrict__ kd,
                               const float* __restrict__ eff_lim, const float* __restrict__ vel_lim,
                               float sat, float* __restrict__ computed, float* __restrict__ applied) {
-    if (blockIdx.x >= nb_act) {
-        scene_update_block(upd, dt, blockIdx.x - nb_act, nb_root, nb_joint, nb_contact);
+    const unsigned nb_upd = gridDim.x - nb_act;   // carried scene update: the first blocks of the grid
+    if (blockIdx.x < nb_upd) {
+        scene_update_block(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact);
         return;
     }
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+    for (int64_t i = (blockIdx.x - nb_upd) * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)nb_act * blockDim.x) {
         int64_t e = i / J;
         int j = (int)(i - e * J);

@@ -16,6 +16,7 @@
 #include "raycaster_update_device.hpp"
 #include "scene_update_device.hpp"
 #include "command_device.hpp"
+#include "stamps_device.hpp"
 
 #include <cstdlib>
 #include <algorithm>
@@ -686,9 +687,12 @@ template <int BATCH>
 __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
+        MDP_STAMP(0, 1);
         raycaster_update_down_blocks<BATCH>(a.cast, a.cast_epb, a.cast_slot_w, blockIdx.x - a.nb_post, a.nb_cast);
+        MDP_STAMP(1);
         return;
     }
+    MDP_STAMP(0, 2);
     const unsigned b = blockIdx.x;
     const int N = a.N;
     const int E = a.post_envs;
@@ -696,19 +700,27 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
     const int e1 = e0 + E < N ? e0 + E : N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int tmax = a.Tt > a.Tr ? a.Tt : a.Tr;
-    float* s_val = reinterpret_cast<float*>(s_dyn);                                   // [tmax][64]
+    // LDS: [tmax][64] term values | observation, termination and reward term tables | column -> term map.  The tables
+    // are staged first (their first use is behind the scene update), so no phase starts with a round trip for its terms
+    float* s_val = reinterpret_cast<float*>(s_dyn);
     mdp_term_t* oterms = reinterpret_cast<mdp_term_t*>(s_dyn + (size_t)(tmax > 0 ? tmax : 1) * 64 * sizeof(float));
-    int16_t* col2term = reinterpret_cast<int16_t*>(reinterpret_cast<unsigned char*>(oterms) + (size_t)a.To * sizeof(mdp_term_t));
-    // observation term table -> LDS (independent of everything below; first use is after several barriers)
-    if (a.obs) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(a.oterms);
+    mdp_term_t* tterms = oterms + a.To;
+    mdp_term_t* rterms = tterms + a.Tt;
+    int16_t* col2term = reinterpret_cast<int16_t*>(rterms + a.Tr);
+    {
+        constexpr int W = (int)(sizeof(mdp_term_t) / 4);
+        const uint32_t* so = reinterpret_cast<const uint32_t*>(a.oterms);
+        const uint32_t* st = reinterpret_cast<const uint32_t*>(a.tterms);
+        const uint32_t* sr = reinterpret_cast<const uint32_t*>(a.rterms);
         uint32_t* dst = reinterpret_cast<uint32_t*>(oterms);
-        const int words = a.To * (int)(sizeof(mdp_term_t) / 4);
-        for (int i = threadIdx.x; i < words; i += blockDim.x) dst[i] = src[i];
+        const int wo = a.To * W, wt = a.Tt * W, wr = a.Tr * W;
+        for (int i = threadIdx.x; i < wo + wt + wr; i += blockDim.x)
+            dst[i] = i < wo ? so[i] : (i < wo + wt ? st[i - wo] : sr[i - wo - wt]);
         for (int i = threadIdx.x; i < a.O; i += blockDim.x) col2term[i] = a.col2term[i];
     }
     // ---- scene.update(physics_dt) for this block's envs (interactive_scene.py:496-513)
     if (a.has_upd) scene_update_envs(a.upd, a.physics_dt, e0, e1);
+    MDP_STAMP(1);
     const int e = lane < E ? e0 + lane : N;   // lanes beyond the block's envs idle through the term phases
     // ---- episode_length_buf += 1 (manager_based_rl_env.py:199)
     if (a.len_inc && wave == 0 && e < N) a.len_inc[e] += 1;
@@ -716,7 +728,7 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
     __syncthreads();
     // ---- terminations (termination_manager.py:151-174): wave w evaluates terms w, w + nwaves, ...
     for (int ti = wave; ti < a.Tt; ti += nwaves) {
-        const mdp_term_t& t = a.tterms[ti];
+        const mdp_term_t& t = tterms[ti];
         bool v = e < N ? term_value(t, a.tpool, e) : false;
         if (a.term_dones && e < N) a.term_dones[(int64_t)t.out_offset * N + e] = v ? 1 : 0;
         s_val[ti * 64 + lane] = v ? 1.0f : 0.0f;
@@ -726,7 +738,7 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
         bool trunc = false, term = false;
         for (int ti = 0; ti < a.Tt; ++ti) {
             bool v = s_val[ti * 64 + lane] != 0.0f;
-            if (a.tterms[ti].i3) trunc = trunc || v; else term = term || v;
+            if (tterms[ti].i3) trunc = trunc || v; else term = term || v;
         }
         if (a.truncated) a.truncated[e] = trunc ? 1 : 0;
         if (a.terminated) a.terminated[e] = term ? 1 : 0;
@@ -734,9 +746,10 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
     }
     __threadfence_block();
     __syncthreads();
+    MDP_STAMP(2);
     // ---- rewards (reward_manager.py:128-157)
     for (int ti = wave; ti < a.Tr; ti += nwaves) {
-        const mdp_term_t& t = a.rterms[ti];
+        const mdp_term_t& t = rterms[ti];
         float value = 0.0f;
         if (e < N && t.weight != 0.0f) {
             value = reward_value(t, a.rpool, e, N) * t.weight * a.step_dt;
@@ -749,12 +762,13 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
     if (wave == 0 && e < N && a.Tr > 0) {
         float total = 0.0f;
         for (int ti = 0; ti < a.Tr; ++ti)
-            if (a.rterms[ti].weight != 0.0f) total += s_val[ti * 64 + lane];
+            if (rterms[ti].weight != 0.0f) total += s_val[ti * 64 + lane];
         a.reward[e] = total;
     }
     // ---- command_manager.compute(step_dt) (command_manager.py:151-187, velocity_command.py:111-160): after the
     // rewards, which read the previous command
     __syncthreads();
+    MDP_STAMP(3);
     if (a.has_cmd) {
         uint64_t seed = 0, epoch = 0;
         const bool gen = a.cmd.rng_state != nullptr && a.cmd.injected_u == nullptr;
@@ -768,6 +782,7 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
         __threadfence_block();
         __syncthreads();
     }
+    MDP_STAMP(4);
     // ---- observations (observation_manager.py:260-335), columns fastest: contiguous row writes
     if (a.obs) {
         uint64_t seed = 0, epoch = 0;
@@ -789,6 +804,7 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
         }
         if (a.ouses_rng && threadIdx.x == 0) a.orng[a.orng_base + b] = epoch + 1;
     }
+    MDP_STAMP(5);
 }
 
 // ---- single-term evaluation: the term travels as a kernel argument (no allocation, no sync) ----
@@ -993,6 +1009,8 @@ extern "C" int mdp_termination_reward_compute(mdp_program_t* tp, mdp_program_t* 
     return MDP_OK;
 }
 
+MDP_STAMP_SETTER(mdp_debug_stamps_programs)
+
 extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float physics_dt,
                                      const mdp_termination_reward_args_t* tr, const mdp_velocity_command_args_t* command,
                                      const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
@@ -1015,7 +1033,7 @@ extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* upd
     }();
     static const int post_envs = [] {
         const char* v = std::getenv("MDP_POST_ENVS");
-        int e = v ? std::atoi(v) : 16;     // measured best on MI355X at 4096 envs
+        int e = v ? std::atoi(v) : 24;     // measured best on MI355X at 4096 envs
         return e < 1 ? 1 : (e > POST_ENVS_MAX ? POST_ENVS_MAX : e);
     }();
     int threads = threads_env > 0 ? threads_env : 256;
@@ -1077,6 +1095,7 @@ extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* upd
     }
     // ---- observations
     size_t lds = (size_t)((a.Tt > a.Tr ? a.Tt : a.Tr) > 0 ? (a.Tt > a.Tr ? a.Tt : a.Tr) : 1) * 64 * sizeof(float);
+    lds += (size_t)(a.Tt + a.Tr) * sizeof(mdp_term_t) + 16;
     if (observation && observation->program) {
         mdp_program_t* op = observation->program;
         MDP_REQUIRE(op->kind == MDP_PROG_OBS && op->num_envs == num_envs, "not an observation program of this size");

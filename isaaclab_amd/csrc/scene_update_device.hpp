@@ -124,54 +124,153 @@ __device__ __forceinline__ void scene_update_block(const mdp_scene_update_t& d, 
 // The same update restricted to the envs [e0, e1), executed by ONE whole block (any blockDim.x): used by the
 // post-physics kernel, whose blocks each own a range of envs for every stage of the step.  Every thread of the block
 // must call it (it contains a barrier).
+//
+// A thread handles one root-state element, one joint and one contact body per round and requests EVERYTHING those three
+// need (sources, previous velocities, bookkeeping words, force, history rows, timers) before it waits for any of it, so
+// a round costs about two memory round trips instead of a dozen chained ones -- the block is one link of a long chain
+// of dependent phases, and every round trip is paid in full.
 __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, float dt, int e0, int e1) {
+    constexpr int TICKS = (int)(sizeof(d.tick_timestamp) / sizeof(d.tick_timestamp[0]));
+    constexpr int HMAX = 4;  // history rows prefetched into registers; longer histories take the in-place shift
     const int n = e1 - e0;
-    if (d.root_state_w) {
-        for (int i = threadIdx.x; i < n * 13; i += blockDim.x) {
+    const int J = d.num_joints, B = d.num_contact_bodies, H = d.history_len;
+    const bool has_root = d.root_state_w != nullptr;
+    const bool has_joint = d.joint_vel_src != nullptr && J > 0;
+    const bool has_contact = d.net_contact_forces != nullptr && B > 0;
+    const bool hist_regs = d.net_forces_w_history != nullptr && H > 0 && H <= HMAX;
+    const int n_root = has_root ? n * 13 : 0, n_joint = has_joint ? n * J : 0, n_contact = has_contact ? n * B : 0;
+    int rounds_items = n_root > n_joint ? n_root : n_joint;
+    if (n_contact > rounds_items) rounds_items = n_contact;
+    for (int base = 0; base < rounds_items; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        const bool hr = i < n_root, hj = i < n_joint, hc = i < n_contact;
+        // ---- requests
+        float rv = 0.0f;
+        int64_t ro = 0;
+        if (hr) {
             int64_t r = e0 + i / 13;
             int k = i % 13;
-            float v;
-            if (k < 3) v = d.root_transforms[7 * r + k];
-            else if (k == 3) v = d.root_transforms[7 * r + 6];
-            else if (k < 7) v = d.root_transforms[7 * r + k - 1];
-            else v = d.root_velocities[6 * r + (k - 7)];
-            d.root_state_w[13 * r + k] = v;
+            ro = 13 * r + k;
+            if (k < 3) rv = d.root_transforms[7 * r + k];
+            else if (k == 3) rv = d.root_transforms[7 * r + 6];
+            else if (k < 7) rv = d.root_transforms[7 * r + k - 1];
+            else rv = d.root_velocities[6 * r + (k - 7)];
         }
-    }
-    if (d.joint_vel_src && d.num_joints > 0) {
-        const int J = d.num_joints;
-        for (int i = threadIdx.x; i < n * J; i += blockDim.x) {
+        float qd = 0.0f, qp = 0.0f, pv = 0.0f;
+        int64_t jo = 0;
+        if (hj) {
             int64_t e = e0 + i / J;
             int j = i % J;
-            int64_t o = e * J + j;
-            float qd = d.joint_vel_src[e * d.ld_joint_src + j];
-            if (d.joint_vel) d.joint_vel[o] = qd;
-            if (d.joint_pos) d.joint_pos[o] = d.joint_pos_src[e * d.ld_joint_src + j];
+            jo = e * J + j;
+            qd = d.joint_vel_src[e * d.ld_joint_src + j];
+            if (d.joint_pos) qp = d.joint_pos_src[e * d.ld_joint_src + j];
+            if (d.joint_acc) pv = d.prev_joint_vel[jo];
+        }
+        int ce = 0, cb = 0;
+        int64_t ci = 0;
+        float ts = 0.0f, tl = 0.0f, ca = 0.0f, cc = 0.0f;
+        uint8_t flag = 0;
+        V3 f = V3{0.0f, 0.0f, 0.0f};
+        V3 hrow[HMAX];
+        if (hc) {
+            ce = e0 + i / B;
+            cb = i % B;
+            ci = (int64_t)ce * B + cb;
+            ts = d.contact_timestamp[ce];
+            tl = d.contact_timestamp_last_update[ce];
+            flag = d.contact_is_outdated[ce];
+            if (d.contact_eager) {
+                f = ld3(d.net_contact_forces + 3 * ci);
+                if (hist_regs) {
+                    const float* hb = d.net_forces_w_history + ((int64_t)ce * H * B + cb) * 3;
+#pragma unroll
+                    for (int s = 0; s < HMAX - 1; ++s)
+                        if (s < H - 1) hrow[s] = ld3(hb + (int64_t)s * B * 3);
+                }
+                if (d.current_air_time) { ca = d.current_air_time[ci]; cc = d.current_contact_time[ci]; }
+            }
+        }
+        // ---- results
+        if (hr) d.root_state_w[ro] = rv;
+        if (hj) {
+            if (d.joint_vel) d.joint_vel[jo] = qd;
+            if (d.joint_pos) d.joint_pos[jo] = qp;
             if (d.joint_acc) {
-                d.joint_acc[o] = (qd - d.prev_joint_vel[o]) / d.acc_elapsed;
-                d.prev_joint_vel[o] = qd;
+                d.joint_acc[jo] = (qd - pv) / d.acc_elapsed;
+                d.prev_joint_vel[jo] = qd;
+            }
+        }
+        if (hc) {
+            float t_new = ts + dt;
+            bool od = (flag != 0) || ((t_new - tl) + 1e-6f >= d.contact_update_period);
+            if (od && d.contact_eager) {
+                const float elapsed = t_new - tl;
+                if (hist_regs || !d.net_forces_w_history || H <= 0) {
+                    // contact_body_update with its inputs already in registers (contact_sensor.py:314-373)
+                    st3(d.net_forces_w + 3 * ci, f);
+                    if (hist_regs) {
+                        float* hb = d.net_forces_w_history + ((int64_t)ce * H * B + cb) * 3;
+#pragma unroll
+                        for (int s = HMAX - 1; s >= 1; --s)
+                            if (s < H) st3(hb + (int64_t)s * B * 3, hrow[s - 1]);
+                        st3(hb, f);
+                    }
+                    if (d.current_air_time) {
+                        bool is_contact = norm3(f) > d.force_threshold;
+                        bool first_contact = (ca > 0.0f) && is_contact;
+                        bool first_detached = (cc > 0.0f) && !is_contact;
+                        if (first_contact) d.last_air_time[ci] = ca + elapsed;
+                        d.current_air_time[ci] = !is_contact ? (ca + elapsed) : 0.0f;
+                        if (first_detached) d.last_contact_time[ci] = cc + elapsed;
+                        d.current_contact_time[ci] = is_contact ? (cc + elapsed) : 0.0f;
+                    }
+                } else {
+                    contact_body_update(ci, ce, cb, B, H, d.net_contact_forces, d.net_forces_w, d.net_forces_w_history,
+                                        d.last_air_time, d.current_air_time, d.last_contact_time, d.current_contact_time,
+                                        elapsed, d.force_threshold);
+                }
             }
         }
     }
-    const bool has_contact = d.net_contact_forces != nullptr && d.num_contact_bodies > 0;
-    if (has_contact) {
-        const int B = d.num_contact_bodies;
-        for (int i = threadIdx.x; i < n * B; i += blockDim.x) {
-            int e = e0 + i / B;
-            int bb = i % B;
-            float t_new = d.contact_timestamp[e] + dt;
-            float t_last = d.contact_timestamp_last_update[e];
-            bool od = (d.contact_is_outdated[e] != 0) || ((t_new - t_last) + 1e-6f >= d.contact_update_period);
-            if (od && d.contact_eager)
-                contact_body_update((int64_t)e * B + bb, e, bb, B, d.history_len, d.net_contact_forces, d.net_forces_w,
-                                    d.net_forces_w_history, d.last_air_time, d.current_air_time, d.last_contact_time,
-                                    d.current_contact_time, t_new - t_last, d.force_threshold);
+    // bookkeeping words: requested before the barrier, committed after it (every body thread has read them by then)
+    float ts = 0.0f, tl = 0.0f;
+    uint8_t flag = 0;
+    const int ee = e0 + (int)threadIdx.x;
+    const bool he = (int)threadIdx.x < n;
+    if (has_contact && he) {
+        ts = d.contact_timestamp[ee];
+        tl = d.contact_timestamp_last_update[ee];
+        flag = d.contact_is_outdated[ee];
+    }
+    float tt[TICKS], ttl[TICKS];
+#pragma unroll
+    for (int s = 0; s < TICKS; ++s) {
+        tt[s] = 0.0f; ttl[s] = 0.0f;
+        if (s < d.num_ticks && he) { tt[s] = d.tick_timestamp[s][ee]; ttl[s] = d.tick_timestamp_last_update[s][ee]; }
+    }
+    __syncthreads();
+    if (has_contact && he) {
+        float t_new = ts + dt;
+        bool od = (flag != 0) || ((t_new - tl) + 1e-6f >= d.contact_update_period);
+        d.contact_timestamp[ee] = t_new;
+        if (od && d.contact_eager) {
+            d.contact_timestamp_last_update[ee] = t_new;
+            od = false;
+        }
+        d.contact_is_outdated[ee] = od ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < TICKS; ++s) {
+        if (s < d.num_ticks && he) {
+            float t = tt[s] + dt;
+            d.tick_timestamp[s][ee] = t;
+            if ((t - ttl[s]) + 1e-6f >= d.tick_update_period[s]) d.tick_is_outdated[s][ee] = 1;
         }
     }
-    __syncthreads();  // every body thread has read the env's bookkeeping words before they are committed
-    if (has_contact) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            int e = e0 + i;
+    // envs beyond blockDim.x (blocks that own more envs than they have threads)
+    for (int i = threadIdx.x + blockDim.x; i < n; i += blockDim.x) {
+        int e = e0 + i;
+        if (has_contact) {
             float t_new = d.contact_timestamp[e] + dt;
             float t_last = d.contact_timestamp_last_update[e];
             bool od = (d.contact_is_outdated[e] != 0) || ((t_new - t_last) + 1e-6f >= d.contact_update_period);
@@ -182,10 +281,7 @@ __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, f
             }
             d.contact_is_outdated[e] = od ? 1 : 0;
         }
-    }
-    for (int s = 0; s < d.num_ticks; ++s) {
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            int e = e0 + i;
+        for (int s = 0; s < d.num_ticks; ++s) {
             float t = d.tick_timestamp[s][e] + dt;
             d.tick_timestamp[s][e] = t;
             if ((t - d.tick_timestamp_last_update[s][e]) + 1e-6f >= d.tick_update_period[s]) d.tick_is_outdated[s][e] = 1;

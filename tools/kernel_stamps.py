@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Where the time goes INSIDE the two big launches of the step (GPU box, diagnostic build):
+
+    make -C isaaclab_amd/csrc STAMPS=1
+    MDP_HIP_LIB=isaaclab_amd/_lib/libmdp_hip_stamps.so python tools/kernel_stamps.py
+
+Every block records wall-clock stamps (100 MHz) at its phase boundaries; the script launches ONE post-physics kernel
+and ONE actuator+scene-update kernel and prints, per block role, when blocks start and finish relative to the first
+block of the launch."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from isaaclab_amd import _lib as L
+from isaaclab_amd.envs.synthetic import make_velocity_env
+
+
+def show(name, st, roles, phases):
+    st = st.cpu().numpy().astype(np.int64)
+    used = st[:, 0] != 0
+    st = st[used]
+    t0 = st[:, 0].min()
+    print(f"== {name}: {used.sum()} blocks, launch span {(st[:, 1:6].max() - t0) / 100.0:.2f} us")
+    for tag, rname in roles.items():
+        r = st[st[:, 7] == tag]
+        if len(r) == 0:
+            continue
+        last = phases[tag]
+        rel = (r[:, : last + 1] - t0) / 100.0
+        line = f"  {rname:<8} n={len(r):5d} start min/med/max {rel[:, 0].min():6.2f}/{np.median(rel[:, 0]):6.2f}/{rel[:, 0].max():6.2f}"
+        line += f"  end min/med/max {rel[:, last].min():6.2f}/{np.median(rel[:, last]):6.2f}/{rel[:, last].max():6.2f}"
+        line += f"  block life med {np.median(rel[:, last] - rel[:, 0]):6.2f} us"
+        print(line)
+        if last > 1:
+            d = np.diff(rel, axis=1)
+            print("           phase medians (us): " + "  ".join(f"{np.median(d[:, k]):.2f}" for k in range(d.shape[1])))
+
+
+def main():
+    env, rec = make_velocity_env("anymal_c_rough", num_envs=4096, device="cuda:0", steps=8, seed=5, inject_random=False)
+    env.observation_manager.persistent_output = True
+    acts = rec.actions.to("cuda:0")
+    for k in range(8):
+        env.step(acts[k % acts.shape[0]])
+    env.scene.sensors["height_scanner"].cfg.update_period = 0.0
+    torch.cuda.synchronize()
+    buf = torch.zeros((8192, 8), dtype=torch.int64, device="cuda:0")
+    for setter in ("mdp_debug_stamps_programs", "mdp_debug_stamps_actuator_nets"):
+        fn = getattr(L.lib, setter)
+        fn.argtypes = [C.c_void_p]
+        fn.restype = C.c_int
+        assert fn(buf.data_ptr()) == 0
+    for rep in range(3):
+        buf.zero_()
+        torch.cuda.synchronize()
+        env._post_physics_single_launch()
+        torch.cuda.synchronize()
+        if rep == 2:
+            show("k_post_physics", buf, {2: "managers", 1: "cast"}, {2: 5, 1: 1})
+    for rep in range(3):
+        buf.zero_()
+        torch.cuda.synchronize()
+        env.scene.update_and_write(env.physics_dt)
+        torch.cuda.synchronize()
+        if rep == 2:
+            show("k_lstm8_reg + scene update", buf, {1: "update", 2: "lstm"}, {1: 1, 2: 1})
+    for rep in range(3):
+        buf.zero_()
+        torch.cuda.synchronize()
+        env.scene["robot"].write_data_to_sim()
+        torch.cuda.synchronize()
+        if rep == 2:
+            show("k_lstm8_reg alone", buf, {2: "lstm"}, {2: 1})
+
+
+if __name__ == "__main__":
+    main()
