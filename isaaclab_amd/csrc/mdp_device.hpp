@@ -161,13 +161,36 @@ MDP_DEV U4 rng4(uint64_t seed, uint64_t epoch, uint32_t stream, uint64_t index) 
     U4 ctr{(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)epoch, stream ^ (uint32_t)(epoch >> 32) * 0x9E3779B9u};
     return philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
+// Per-element observation noise draws one number for every output element of every step (and one per ray in the
+// height scan): Philox's 40 quarter-rate integer multiplies per draw were a fifth of the cast kernel's vector time.
+// These draws use a two-round multiply-xorshift finaliser (constants from the hash-prospector search, avalanche bias
+// ~0.1) over (element index ^ key), the key being the same finaliser chained over seed, stream id and epoch -- still
+// counter-based and stateless, ~1/8 of the instructions.  The command sampler (rare, few numbers) stays on Philox.
+MDP_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x21f0aaadu;
+    x ^= x >> 15; x *= 0x735a2d97u;
+    x ^= x >> 15;
+    return x;
+}
+MDP_DEV uint32_t rng_key(uint64_t seed, uint64_t epoch, uint32_t stream) {   // uniform over a launch
+    uint32_t k = mix32((uint32_t)seed ^ 0x9E3779B9u);
+    k = mix32(k ^ (uint32_t)(seed >> 32));
+    k = mix32(k ^ stream);
+    k = mix32(k ^ (uint32_t)epoch);
+    k = mix32(k ^ (uint32_t)(epoch >> 32));
+    return k;
+}
+MDP_DEV uint32_t rng_bits(uint32_t key, uint64_t index, uint32_t salt) {
+    uint32_t x = mix32((uint32_t)index ^ key);
+    return mix32(x ^ ((uint32_t)(index >> 32) * 0x85EBCA6Bu + salt));
+}
 MDP_DEV float rng_uniform(uint64_t seed, uint64_t epoch, uint32_t stream, uint64_t index) {
-    return u01(rng4(seed, epoch, stream, index).x);
+    return u01(rng_bits(rng_key(seed, epoch, stream), index, 0x68E31DA4u));
 }
 MDP_DEV float rng_normal(uint64_t seed, uint64_t epoch, uint32_t stream, uint64_t index) {
-    U4 r = rng4(seed, epoch, stream, index);
-    float u1 = 1.0f - u01(r.x);  // (0,1]
-    float u2 = u01(r.y);
+    uint32_t key = rng_key(seed, epoch, stream);
+    float u1 = 1.0f - u01(rng_bits(key, index, 0x68E31DA4u));  // (0,1]
+    float u2 = u01(rng_bits(key, index, 0xB5297A4Du));
     return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
 }
 

@@ -327,6 +327,9 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     v.cell_start = d_cs;
     v.cell_tris = d_ct;
     v.cell_recs = d_recs;
+    v.finite = 1;
+    for (size_t i = 0; i < tv.size(); ++i)
+        if (!std::isfinite(tv[i])) { v.finite = 0; break; }
     v.gx0 = gx0; v.gy0 = gy0; v.cell = cellf; v.inv_cell = 1.0f / cellf;
     v.ncx = ncx; v.ncy = ncy;
     v.zmin = mn[2]; v.zmax = mx[2];

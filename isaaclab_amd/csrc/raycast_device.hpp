@@ -41,6 +41,7 @@ typedef struct {
     // A ray reads ONE contiguous run per visited cell instead of chasing cell_tris -> tri_verts, and a
     // downward ray stops at the first record that lies entirely below its current best hit.
     const float* cell_recs;
+    int32_t finite;  // every vertex coordinate is finite (device builder; lets vertical rays drop their zero products)
 } mdp_mesh_view_t;
 
 typedef struct {
@@ -363,6 +364,71 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, 
                     best.face = f;
                 }
             }
+        }
+    }
+    return best;
+}
+// mdp_rc_grid_down for an EXACTLY vertical ray (d.x == d.y == 0, d.z < 0) on a mesh with finite vertices, with the
+// arithmetic that cannot change a result removed (the cast kernel is bound by vector instructions, not by memory):
+//   * Sx = d.y / d.z and Sy = d.x / d.z are zeros, so Sx * Az3 is a zero and Ax = Ay3 - Sx * Az3 == Ay3 bit for bit for
+//     every non-zero Ay3 (a zero Ay3 may come out with the other sign, which no later product, sum with a non-zero
+//     term or comparison against 0 can see);
+//   * the z-slab clip only prunes: a triangle hit needs 0 <= t < max_t on its own.
+// Same records, same order, same early exit, same t as mdp_rc_grid_down / mdp_rc_grid (the CPU oracle's path).
+template <int BATCH>
+__device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_t* m, float ox, float oy, float oz, float dz,
+                                                            float max_t) {
+    mdp_hit_t best; best.t = max_t; best.face = -1;
+    float pad = 1e-3f * m->cell + 1e-6f;
+    float hix = m->gx0 + m->cell * (float)m->ncx, hiy = m->gy0 + m->cell * (float)m->ncy;
+    if (ox < m->gx0 - pad || ox > hix + pad) return best;
+    if (oy < m->gy0 - pad || oy > hiy + pad) return best;
+    int cx = (int)floorf((ox - m->gx0) * m->inv_cell);
+    int cy = (int)floorf((oy - m->gy0) * m->inv_cell);
+    if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
+    if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
+    int32_t c = cy * m->ncx + cx;
+    int32_t b = m->cell_start[c], e = m->cell_start[c + 1];
+    const float Sz = 1.0f / dz;
+    int stop = 0;
+    for (int32_t k = b; k < e && !stop; k += BATCH) {
+        mdp_rec_t R[BATCH];
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            int32_t kk = k + i < e ? k + i : e - 1;
+            R[i] = mdp_rc_load_rec(m->cell_recs + 12 * (int64_t)kk);
+        }
+#pragma unroll
+        for (int i = 0; i < BATCH; ++i) {
+            if (k + i >= e || stop) continue;
+            const float* tv = R[i].v;
+            if (best.face >= 0) {
+                float t_reach = (tv[10] - oz) * Sz;
+                if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = 1; continue; }
+            }
+            float Ax = tv[1] - oy, Ay = tv[0] - ox;
+            float Bx = tv[4] - oy, By = tv[3] - ox;
+            float Cx = tv[7] - oy, Cy = tv[6] - ox;
+            float U = Cx * By - Cy * Bx;
+            float V = Ax * Cy - Ay * Cx;
+            float W = Bx * Ay - By * Ax;
+            if (U == 0.0f || V == 0.0f || W == 0.0f) {
+                double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+                U = (float)(CxBy - CyBx);
+                double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+                V = (float)(AxCy - AyCx);
+                double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+                W = (float)(BxAy - ByAx);
+            }
+            if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) continue;
+            float det = (U + V) + W;
+            if (det == 0.0f) continue;
+            float Az = Sz * (tv[2] - oz), Bz = Sz * (tv[5] - oz), Cz = Sz * (tv[8] - oz);
+            float T = (U * Az + V * Bz) + W * Cz;
+            if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) continue;
+            float rcp = 1.0f / det;
+            float t = T * rcp;
+            if (t >= 0.0f && t < best.t) { best.t = t; best.face = 0; }   // ties on t do not change t
         }
     }
     return best;

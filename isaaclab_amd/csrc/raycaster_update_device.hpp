@@ -5,6 +5,7 @@
 #include "mdp_device.hpp"
 #include "raycast_device.hpp"
 #include "obs_post_device.hpp"
+#include "stamps_device.hpp"
 
 namespace mdp {
 
@@ -37,60 +38,80 @@ __device__ __forceinline__ void scan_store(const mdp_height_scan_obs_t& sc, int 
 
 // yaw-only attachment and a pattern whose directions are all (0, 0, -c), on a mesh with cell records.  A block owns
 // epb whole environments (slot_w threads each, blockDim.x >= epb * slot_w) and strides over the envs by nblocks.
+//
+// The kernel is bound by vector instructions, so everything that is per ENV runs on one lane per env -- the sensor
+// bookkeeping of this physics step, the pose, the yaw quaternion (atan2f / cosf / sinf) -- and reaches the env's ray
+// lanes through LDS behind the block's single barrier; the ray lanes only rotate their start, walk one grid cell and
+// post-process their height.
+constexpr int RCU_MAX_EPB = 256;   // blockDim.x <= 1024 and num_rays >= 1; callers keep epb <= this
+
 template <int BATCH>
 __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpdateArgs& a, int epb, int slot_w,
                                                              unsigned block, unsigned nblocks) {
+    __shared__ float s_env[RCU_MAX_EPB][6];   // pos.xyz, yaw quaternion (w, z), cast flag
     const mdp_mesh_view_t& mesh = a.mesh;
-    const int N = a.N, R = a.R, ld_pose = a.ld_pose, pose_xyzw = a.pose_xyzw;
-    const float* __restrict__ pose = a.pose;
-    const float* __restrict__ drift = a.drift;
+    const int N = a.N, R = a.R;
     const float* __restrict__ starts_l = a.starts_l;
     const float* __restrict__ dirs_l = a.dirs_l;
-    const float max_dist = a.max_dist, tick_dt = a.tick_dt, period = a.period;
-    float* __restrict__ pos_w = a.pos_w;
-    float* __restrict__ quat_w = a.quat_w;
     float* __restrict__ hits = a.hits;
-    float* __restrict__ ts = a.ts;
-    float* __restrict__ ts_last = a.ts_last;
-    uint8_t* __restrict__ outdated = a.outdated;
     const mdp_height_scan_obs_t& scan = a.scan;
     const float inf = __builtin_inff();
-    int le = threadIdx.x / slot_w;
-    int lr = threadIdx.x - le * slot_w;
+    const int le = threadIdx.x / slot_w;
+    const int lr = threadIdx.x - le * slot_w;
     uint64_t seed = 0, epoch = 0;
     if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + block]; }
     for (int base = block * epb; base < N; base += nblocks * epb) {
-        int e = base + le;
-        bool active = le < epb && e < N;
-        if (tick_dt > 0.0f) {
-            // SensorBase.update of this physics step (sensor_base.py:197-205) done here, so the cast does not have
-            // to wait for the launch that updates the rest of the scene
-            if (active && lr == 0) {
-                float t = ts[e] + tick_dt;
-                ts[e] = t;
-                if ((t - ts_last[e]) + 1e-6f >= period) outdated[e] = 1;
+        const int e = base + le;
+        const bool active = le < epb && e < N;
+        if (active && lr == 0) {
+            // SensorBase.update of this physics step (sensor_base.py:197-205) + the lazy-evaluation test (:284-293)
+            bool od = a.outdated ? a.outdated[e] != 0 : true;
+            float t_now = a.ts ? a.ts[e] : 0.0f;
+            if (a.tick_dt > 0.0f) {
+                t_now += a.tick_dt;
+                a.ts[e] = t_now;
+                if ((t_now - a.ts_last[e]) + 1e-6f >= a.period) od = true;
             }
-            __syncthreads();
+            float* se = s_env[le];
+            se[5] = od ? 1.0f : 0.0f;
+            if (od) {
+                const float* p = a.pose + (int64_t)e * a.ld_pose;
+                V3 pos = ld3(p);
+                if (a.drift) { pos.x += a.drift[3 * e]; pos.y += a.drift[3 * e + 1]; pos.z += a.drift[3 * e + 2]; }
+                // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows (w, x, y, z)
+                Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+                Q4 qr = yaw_quat(q);
+                se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
+                st3(a.pos_w + 3 * (int64_t)e, pos);
+                st4(a.quat_w + 4 * (int64_t)e, q);
+                if (a.ts_last) a.ts_last[e] = t_now;
+                if (a.outdated) a.outdated[e] = 0;
+            }
         }
-        bool od = active && (outdated ? outdated[e] != 0 : true);
         __syncthreads();
+        MDP_STAMP(2);
+        const float* se = s_env[active ? le : 0];
+        const bool od = active && se[5] != 0.0f;
         if (active && !od && scan.obs) {
-            float sz = pos_w[3 * (int64_t)e + 2];
+            float sz = a.pos_w[3 * (int64_t)e + 2];
             for (int r = lr; r < R; r += slot_w) scan_store(scan, e, r, R, sz, hits[((int64_t)e * R + r) * 3 + 2], seed, epoch);
         }
         if (od) {
-            const float* p = pose + (int64_t)e * ld_pose;
-            V3 pos = ld3(p);
-            if (drift) { pos.x += drift[3 * e]; pos.y += drift[3 * e + 1]; pos.z += drift[3 * e + 2]; }
-            // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows are (w, x, y, z)
-            Q4 q = pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
-            Q4 qr = yaw_quat(q);
+            const V3 pos = V3{se[0], se[1], se[2]};
+            const Q4 qr = Q4{se[3], 0.0f, 0.0f, se[4]};
+            MDP_STAMP(3);
             for (int r = lr; r < R; r += slot_w) {
                 V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
                 s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
                 V3 d = ld3(dirs_l + 3 * r);
-                mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
-                mdp_hit_t h = mdp_rc_grid_down<BATCH>(&mesh, &ray, max_dist);
+                mdp_hit_t h;
+                if (mesh.finite) {
+                    h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist);
+                } else {
+                    mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
+                    h = mdp_rc_grid_down<BATCH>(&mesh, &ray, a.max_dist);
+                }
+                MDP_STAMP(4);
                 float* o = hits + ((int64_t)e * R + r) * 3;
                 float hz = inf;
                 if (h.face >= 0) {
@@ -101,13 +122,8 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
                 }
                 if (scan.obs) scan_store(scan, e, r, R, pos.z, hz, seed, epoch);
             }
-            if (lr == 0) {
-                st3(pos_w + 3 * (int64_t)e, pos);
-                st4(quat_w + 4 * (int64_t)e, q);
-                if (ts_last) ts_last[e] = ts[e];
-                if (outdated) outdated[e] = 0;
-            }
         }
+        __syncthreads();   // s_env is rewritten by the next env group
     }
     if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
 }

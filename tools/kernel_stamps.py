@@ -40,6 +40,19 @@ def show(name, st, roles, phases):
             print("           phase medians (us): " + "  ".join(f"{np.median(d[:, k]):.2f}" for k in range(d.shape[1])))
 
 
+def cast_phases(st):
+    """cast blocks: slots 0 start, 2 flags known (two barriers), 3 pose + yaw quaternion, 4 cell walk done, 1 end"""
+    st = st.cpu().numpy().astype(np.int64)
+    r = st[(st[:, 0] != 0) & (st[:, 7] == 1)]
+    seq = r[:, [0, 2, 3, 4, 1]] / 100.0
+    d = np.diff(seq, axis=1)
+    print("           cast phase medians (us): bookkeeping+barriers %.2f  pose+yaw %.2f  ray setup+cell walk %.2f  hit/obs stores %.2f"
+          % tuple(np.median(d, axis=0)))
+    early = r[:, 0] < np.percentile(r[:, 0], 25)
+    print("           first-quarter blocks: " + "  ".join("%.2f" % v for v in np.median(d[early], axis=0)),
+          "| last-quarter blocks: " + "  ".join("%.2f" % v for v in np.median(d[r[:, 0] > np.percentile(r[:, 0], 75)], axis=0)))
+
+
 def main():
     env, rec = make_velocity_env("anymal_c_rough", num_envs=4096, device="cuda:0", steps=8, seed=5, inject_random=False)
     env.observation_manager.persistent_output = True
@@ -61,6 +74,7 @@ def main():
         torch.cuda.synchronize()
         if rep == 2:
             show("k_post_physics", buf, {2: "managers", 1: "cast"}, {2: 5, 1: 1})
+            cast_phases(buf)
     for rep in range(3):
         buf.zero_()
         torch.cuda.synchronize()
