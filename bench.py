@@ -97,9 +97,12 @@ def algorithmic_bytes(env) -> dict:
         # sub-step before them, and everything after the last physics step is ONE launch (mdp_post_physics_step)
         act, upd = table["actuator"][0], table["scene_update"][0]
         post = upd + sum(table[k][0] for k in ("term_reward", "command", "observation", "raycast"))
+        folded = env.fold_action and env.action_manager._fused_term is not None \
+            and env.action_manager._fused_term.can_fold_into_actuator()
         table = {
-            "action": table["action"],
-            "actuator": (act, 1, table["actuator"][2]),
+            # the first actuator launch of the step also processes the action (mdp_actuator_*_compute_with_action)
+            **({"action+actuator": (table["action"][0] + act, 1, table["actuator"][2])} if folded else
+               {"action": table["action"], "actuator": (act, 1, table["actuator"][2])}),
             "actuator+scene_update": (act + upd, D - 1, table["actuator"][2]),
             "post_physics": (post, 1, "k_post_physics"),
         }
@@ -279,14 +282,22 @@ def measure_roofline(env, args) -> dict:
         hs = sensors["height_scanner"]
         period = hs.cfg.update_period
         hs.cfg.update_period = 0.0          # every timed launch must cast (the step casts once per env-step)
+        raw_action = env.action_manager.action.clone()
+
+        def action_actuator():
+            env.scene.write_data_to_sim(joint_action=env.action_manager.deferred_action(raw_action))
+
         fns = {
-            "action": lambda: env.action_manager.process_action(env.action_manager.action),
+            "action": lambda: env.action_manager.process_action(raw_action),
             "actuator": lambda: robot.write_data_to_sim(),
+            "action+actuator": action_actuator,
             "actuator+scene_update": lambda: env.scene.update_and_write(env.physics_dt),
             "post_physics": lambda: env._post_physics_single_launch(),
         }
         per_kernel = {}
         for name, fn in fns.items():
+            if name not in table:
+                continue
             dur = _graph_time(fn)
             nbytes, launches, frag = table[name]
             per_kernel[name] = {"kernel": frag, "us": 1e6 * dur, "launches_per_step": launches,

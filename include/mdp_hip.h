@@ -458,6 +458,22 @@ int mdp_joint_action_process(int num_envs, int action_dim, const float* actions_
                              const float* scale_vec, float scale, const float* offset /* (N,A) or NULL */,
                              const float* clip /* (N,A,2) or NULL */, void* stream);
 
+/* The arguments of mdp_joint_action_process as one record, for the actuator entry points below that process the action
+ * of the step inside the first actuator launch of the step. */
+typedef struct {
+    const float* actions_in;
+    int32_t ld_in;
+    int32_t pad0;
+    float* action;
+    float* prev_action;
+    float* processed;       /* (N,A), required: it is the joint position target the actuator reads */
+    const float* scale_vec;
+    float scale;
+    int32_t pad1;
+    const float* offset;
+    const float* clip;
+} mdp_joint_action_t;
+
 /* ------------------------------------------------------------------------------------------
  * isaaclab.utils.math kernels (LAB/utils/math.py) -- op ids in enum, generic batched launcher.
  * a/b/c are input rows with widths given per op; out width given per op (see mathops.hip table).
@@ -552,6 +568,25 @@ int mdp_stats_moments(const float* x, int num_envs, int dim, int ld, double* out
  * out[2*k] = sum_{mask} values[k][env], out[2*k+1] = count, for k rows of a (K,N) matrix. */
 int mdp_stats_masked_sums(const float* values, int rows, int num_envs, const uint8_t* mask, double* out,
                           void* stream);
+
+/* ManagerBasedRLEnv.step lines 168-186 for a joint-position action term that drives every joint of an articulation with
+ * one actuator group: action_manager.process_action(action) (mdp_joint_action_process), apply_action() (the processed
+ * action IS the joint position target) and the first scene.write_data_to_sim() of the step
+ * (mdp_actuator_lstm_compute / mdp_actuator_pd_compute with q_des = action->processed, ld = num_joints) as ONE launch:
+ * each (env, joint) row processes its own action element before it evaluates the actuator.  action_dim == num_joints.
+ * Outputs are bit-identical to the two separate calls. */
+int mdp_actuator_lstm_compute_with_action(const mdp_joint_action_t* action, const mdp_net_desc_t* desc,
+                                          const float* packed_weights, int num_envs, int num_joints,
+                                          const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                          float* hidden_state, float* cell_state, const float* effort_limit,
+                                          const float* velocity_limit, float saturation_effort, float* computed_effort,
+                                          float* applied_effort, void* stream);
+int mdp_actuator_pd_compute_with_action(const mdp_joint_action_t* action, int kind, int num_envs, int num_joints,
+                                        const float* qd_des, int ld_qd_des, const float* tau_ff, int ld_tau_ff,
+                                        const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                        const float* stiffness, const float* damping, const float* effort_limit,
+                                        const float* velocity_limit, float saturation_effort, float* computed_effort,
+                                        float* applied_effort, void* stream);
 
 /* Everything ManagerBasedRLEnv.step does after its last physics sub-step, for a height-scan locomotion task, as ONE
  * launch (manager_based_rl_env.py:195-238 without the reset branch):

@@ -126,6 +126,16 @@ class MdpRaycasterUpdateArgs(C.Structure):
     ]
 
 
+class MdpJointAction(C.Structure):
+    """Mirror of ``mdp_joint_action_t``."""
+
+    _fields_ = [
+        ("actions_in", C.c_void_p), ("ld_in", C.c_int32), ("pad0", C.c_int32), ("action", C.c_void_p),
+        ("prev_action", C.c_void_p), ("processed", C.c_void_p), ("scale_vec", C.c_void_p), ("scale", C.c_float),
+        ("pad1", C.c_int32), ("offset", C.c_void_p), ("clip", C.c_void_p),
+    ]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -114,6 +114,23 @@ class ActuatorBase(ABC):
     #: (``mdp_actuator_*_compute_after_update``); set by ``Articulation`` right before ``compute``
     carries_scene_update: bool = False
     pending_scene_update = None
+    #: whether ``compute`` can process the step's joint-position action in its own launch
+    #: (``mdp_actuator_*_compute_with_action``); ``Articulation`` sets ``pending_joint_action`` right before ``compute``
+    folds_joint_action: bool = False
+    pending_joint_action = None
+
+    def _take_joint_action(self, q_des_ptr, ld_q_des):
+        """The pending joint action if this launch can process it (its processed buffer IS the position target the
+        launch reads); otherwise processes it with its own launch and returns None."""
+        act, self.pending_joint_action = self.pending_joint_action, None
+        if act is None:
+            return None
+        if self.pending_scene_update is None and q_des_ptr == act.processed and ld_q_des == self.num_joints:
+            return act
+        L.check(L.lib.mdp_joint_action_process(
+            self._num_envs, self.num_joints, act.actions_in, act.ld_in, act.action, act.prev_action, act.processed,
+            act.scale_vec, act.scale, act.offset, act.clip, L.stream()))
+        return None
 
     def _pd_launch(self, kind: str, control_action: ArticulationActions, joint_pos: torch.Tensor,
                    joint_vel: torch.Tensor, saturation: float = torch.inf):
@@ -138,6 +155,14 @@ class ActuatorBase(ABC):
             if not p.is_contiguous():
                 setattr(self, name, p.contiguous())
         # a pending scene update (scene.update of the frame being read) rides along in the same launch
+        act = self._take_joint_action(args[0], args[1])
+        if act is not None:
+            L.check(L.lib.mdp_actuator_pd_compute_with_action(
+                C.byref(act), L.ACT_KINDS[kind], self._num_envs, self.num_joints, *args[2:], q.data_ptr(), ld_q,
+                qd.data_ptr(), ld_qd, self.stiffness.data_ptr(), self.damping.data_ptr(), self.effort_limit.data_ptr(),
+                self.velocity_limit.data_ptr(), float(saturation), self.computed_effort.data_ptr(),
+                self.applied_effort.data_ptr(), L.stream(q.device)))
+            return
         upd, self.pending_scene_update = self.pending_scene_update, None
         L.check(L.lib.mdp_actuator_pd_compute_after_update(
             C.byref(upd[0]) if upd is not None else None, float(upd[1]) if upd is not None else 0.0,

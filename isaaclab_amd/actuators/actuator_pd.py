@@ -14,6 +14,7 @@ class ImplicitActuator(ActuatorBase):
     """actuator_pd.py:32-87: returns the action unchanged, stores the approximate torques."""
 
     carries_scene_update = True
+    folds_joint_action = True
 
     def reset(self, *args, **kwargs):
         pass
@@ -27,6 +28,7 @@ class IdealPDActuator(ActuatorBase):
     """actuator_pd.py:95-145"""
 
     carries_scene_update = True
+    folds_joint_action = True
 
     def reset(self, env_ids: Sequence[int]):
         pass
@@ -61,6 +63,8 @@ class DCMotor(IdealPDActuator):
 
 class DelayedPDActuator(IdealPDActuator):
     """actuator_pd.py:236-293: per-env integer command lag (three delay buffers)."""
+
+    folds_joint_action = False   # the delay buffers read the processed targets before the PD launch
 
     def __init__(self, cfg, *args, **kwargs):
         super().__init__(cfg, *args, **kwargs)

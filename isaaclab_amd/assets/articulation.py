@@ -80,10 +80,17 @@ class Articulation:
         for actuator in self.actuators.values():
             actuator.reset(env_ids)
 
-    def write_data_to_sim(self, carry_update=None):
+    def write_data_to_sim(self, carry_update=None, joint_action=None):
         """articulation.py:172-199 (the physics-side setters are out of scope).  ``carry_update = (desc, dt)`` lets the
-        actuator launch run the scene update of the frame it reads in the same kernel (``can_carry_update``)."""
-        self._apply_actuator_model(carry_update)
+        actuator launch run the scene update of the frame it reads in the same kernel (``can_carry_update``);
+        ``joint_action`` (``L.MdpJointAction``) lets it process the action of the step (``can_fold_joint_action``)."""
+        self._apply_actuator_model(carry_update, joint_action)
+
+    @property
+    def can_fold_joint_action(self) -> bool:
+        if not getattr(self, "_single_full_group", False):
+            return False
+        return bool(getattr(next(iter(self.actuators.values())), "folds_joint_action", False))
 
     @property
     def can_carry_update(self) -> bool:
@@ -181,7 +188,7 @@ class Articulation:
                 return
         self._single_full_group = False
 
-    def _apply_actuator_model(self, carry_update=None):
+    def _apply_actuator_model(self, carry_update=None, joint_action=None):
         """articulation.py:1399-1436"""
         d = self._data
         if carry_update is not None:
@@ -193,6 +200,7 @@ class Articulation:
         for actuator in self.actuators.values():
             ji = actuator.joint_indices
             actuator.pending_scene_update = carry_update
+            actuator.pending_joint_action = joint_action
             control_action = ArticulationActions(
                 joint_positions=d.joint_pos_target[:, ji], joint_velocities=d.joint_vel_target[:, ji],
                 joint_efforts=d.joint_effort_target[:, ji], joint_indices=ji,

@@ -15,6 +15,7 @@
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
 #include "stamps_device.hpp"
+#include "joint_action_device.hpp"
 #include "scene_update_device.hpp"
 
 #include <cstdlib>
@@ -178,7 +179,7 @@ MDP_DEV void dc_clip_store(float tau, float qd, int64_t row, const float* __rest
 template <int H>
 __global__ void __launch_bounds__(256)
 k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
-       NetDev net, const float* __restrict__ packed, int64_t rows, int J,
+       mdp_joint_action_t jact, NetDev net, const float* __restrict__ packed, int64_t rows, int J,
        const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
        const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
        const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
@@ -213,8 +214,9 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
         rr = valid ? row : rows - 1;
         int64_t e = rr / J;
         int j = (int)(rr - e * J);
-        // actuator_net.py:80-81
-        x0 = q_des[e * ld_q_des + j] - q[e * ld_q + j];
+        // actuator_net.py:80-81 (jact.actions_in: this launch also processes the action of the step)
+        float des = jact.actions_in ? joint_action_element(jact, e, j, J, valid && gq == 0) : q_des[e * ld_q_des + j];
+        x0 = des - q[e * ld_q + j];
         x1 = qd[e * ld_qd + j];
 #pragma unroll
         for (int l = 0; l < LMAX; ++l) {
@@ -303,7 +305,7 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
 template <int NL>
 __global__ void __launch_bounds__(256)
 k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
-            NetDev net, const float* __restrict__ packed, int64_t rows, int J,
+            mdp_joint_action_t jact, NetDev net, const float* __restrict__ packed, int64_t rows, int J,
             const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
             const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
             const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
@@ -335,7 +337,9 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
         rr = valid ? row : rows - 1;
         int64_t e = rr / J;
         int j = (int)(rr - e * J);
-        x0 = q_des[e * ld_q_des + j] - q[e * ld_q + j];  // actuator_net.py:80-81
+        // actuator_net.py:80-81 (jact.actions_in: this launch also processes the action of the step)
+        float des = jact.actions_in ? joint_action_element(jact, e, j, J, valid && gq == 0) : q_des[e * ld_q_des + j];
+        x0 = des - q[e * ld_q + j];
         x1 = qd[e * ld_qd + j];
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -577,7 +581,7 @@ static unsigned net_grid(int64_t rows) {
 
 MDP_STAMP_SETTER(mdp_debug_stamps_actuator_nets)
 
-extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* update, float dt,
+static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_t* update, float dt,
                                                       const mdp_net_desc_t* desc, const float* packed_weights,
                                                       int num_envs, int num_joints, const float* q_des, int ld_q_des,
                                                       const float* joint_pos, int ld_pos, const float* joint_vel,
@@ -603,6 +607,14 @@ extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* 
         if (update) return mdp_scene_update(update, dt, stream);
         return MDP_OK;
     }
+    mdp_joint_action_t act;
+    std::memset(&act, 0, sizeof(act));
+    if (action) {
+        MDP_REQUIRE(action->actions_in && action->action && action->processed, "joint action: null pointer");
+        MDP_REQUIRE(action->ld_in >= num_joints, "Invalid action shape, expected: %d, received: %d.", num_joints,
+                    action->ld_in);
+        act = *action;
+    }
     NetDev net;
     net.d = *desc;
     make_layout(*desc, net.L);
@@ -618,7 +630,7 @@ extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* 
             MDP_CHECK_HIP(hipFuncSetAttribute((const void*)k_lstm<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)lds_bytes));                                                    \
         hipLaunchKernelGGL(k_lstm<HH>, grid, block, lds_bytes, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint, \
-                           plan.nb_contact, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,     \
+                           plan.nb_contact, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,     \
                            ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,      \
                            saturation_effort, computed_effort, applied_effort);                                    \
     } while (0)
@@ -627,12 +639,12 @@ extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* 
     if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1) {
         if (desc->lstm_layers == 1)
             hipLaunchKernelGGL(k_lstm8_reg<1>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
-                               plan.nb_contact, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                               plan.nb_contact, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
                                joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
                                saturation_effort, computed_effort, applied_effort);
         else
             hipLaunchKernelGGL(k_lstm8_reg<2>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
-                               plan.nb_contact, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                               plan.nb_contact, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
                                joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
                                saturation_effort, computed_effort, applied_effort);
         MDP_LAUNCH_CHECK();
@@ -647,6 +659,32 @@ extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* 
 #undef LAUNCH
     MDP_LAUNCH_CHECK();
     return MDP_OK;
+}
+
+extern "C" int mdp_actuator_lstm_compute_after_update(const mdp_scene_update_t* update, float dt,
+                                                      const mdp_net_desc_t* desc, const float* packed_weights,
+                                                      int num_envs, int num_joints, const float* q_des, int ld_q_des,
+                                                      const float* joint_pos, int ld_pos, const float* joint_vel,
+                                                      int ld_vel, float* hidden_state, float* cell_state,
+                                                      const float* effort_limit, const float* velocity_limit,
+                                                      float saturation_effort, float* computed_effort,
+                                                      float* applied_effort, void* stream) {
+    return lstm_launch(nullptr, update, dt, desc, packed_weights, num_envs, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                       joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit, saturation_effort,
+                       computed_effort, applied_effort, stream);
+}
+
+extern "C" int mdp_actuator_lstm_compute_with_action(const mdp_joint_action_t* action, const mdp_net_desc_t* desc,
+                                                     const float* packed_weights, int num_envs, int num_joints,
+                                                     const float* joint_pos, int ld_pos, const float* joint_vel,
+                                                     int ld_vel, float* hidden_state, float* cell_state,
+                                                     const float* effort_limit, const float* velocity_limit,
+                                                     float saturation_effort, float* computed_effort,
+                                                     float* applied_effort, void* stream) {
+    MDP_REQUIRE(action, "null joint action");
+    return lstm_launch(action, nullptr, 0.0f, desc, packed_weights, num_envs, num_joints, action->processed, num_joints,
+                       joint_pos, ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
+                       saturation_effort, computed_effort, applied_effort, stream);
 }
 
 extern "C" int mdp_actuator_lstm_compute(const mdp_net_desc_t* desc, const float* packed_weights, int num_envs,

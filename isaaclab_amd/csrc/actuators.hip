@@ -3,6 +3,7 @@
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
 #include "scene_update_device.hpp"
+#include "joint_action_device.hpp"
 
 using namespace mdp;
 
@@ -15,7 +16,7 @@ namespace {
 template <int KIND>
 __global__ void __launch_bounds__(256)
 k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
-              int64_t total, int J,
+              mdp_joint_action_t act, int64_t total, int J,
                               const float* __restrict__ q_des, int ld_q_des,
                               const float* __restrict__ qd_des, int ld_qd_des,
                               const float* __restrict__ tau_ff, int ld_tau_ff,
@@ -35,7 +36,9 @@ k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_roo
         int j = (int)(i - e * J);
         float qv = q[e * ld_q + j];
         float qdv = qd[e * ld_qd + j];
-        float des = q_des ? q_des[e * ld_q_des + j] : 0.0f;
+        // act.actions_in: this launch also processes the action of the step (its processed value is q_des)
+        float des = act.actions_in ? joint_action_element(act, e, j, J, true)
+                                   : (q_des ? q_des[e * ld_q_des + j] : 0.0f);
         float ddes = qd_des ? qd_des[e * ld_qd_des + j] : 0.0f;
         float ff = tau_ff ? tau_ff[e * ld_tau_ff + j] : 0.0f;
         // actuator_pd.py:135-138
@@ -143,7 +146,7 @@ __global__ void k_linear_interp(const float* __restrict__ x, const float* __rest
 
 }  // namespace
 
-extern "C" int mdp_actuator_pd_compute_after_update(const mdp_scene_update_t* update, float dt, int kind, int num_envs,
+static int pd_launch(const mdp_joint_action_t* action, const mdp_scene_update_t* update, float dt, int kind, int num_envs,
                                                     int num_joints, const float* q_des, int ld_q_des,
                                                     const float* qd_des, int ld_qd_des, const float* tau_ff,
                                                     int ld_tau_ff, const float* joint_pos, int ld_pos,
@@ -167,6 +170,14 @@ extern "C" int mdp_actuator_pd_compute_after_update(const mdp_scene_update_t* up
                 "mdp_actuator_pd_compute: null required pointer");
     MDP_REQUIRE(ld_pos >= num_joints && ld_vel >= num_joints, "row stride smaller than num_joints");
     MDP_REQUIRE(kind != MDP_ACT_DC_MOTOR || velocity_limit, "DC motor needs velocity_limit");
+    mdp_joint_action_t act;
+    std::memset(&act, 0, sizeof(act));
+    if (action) {
+        MDP_REQUIRE(action->actions_in && action->action && action->processed, "joint action: null pointer");
+        MDP_REQUIRE(action->ld_in >= num_joints, "Invalid action shape, expected: %d, received: %d.", num_joints,
+                    action->ld_in);
+        act = *action;
+    }
     int64_t total = (int64_t)num_envs * num_joints;
     const int block = 256;
     unsigned nb_act = grid_for(total, block);
@@ -174,7 +185,7 @@ extern "C" int mdp_actuator_pd_compute_after_update(const mdp_scene_update_t* up
     hipStream_t s = as_stream(stream);
 #define LAUNCH(K)                                                                                              \
     hipLaunchKernelGGL(k_actuator_pd<K>, dim3(grid), dim3(block), 0, s, plan.d, dt, nb_act, plan.nb_root,      \
-                       plan.nb_joint, plan.nb_contact, total, num_joints, q_des, ld_q_des, qd_des, ld_qd_des,   \
+                       plan.nb_joint, plan.nb_contact, act, total, num_joints, q_des, ld_q_des, qd_des, ld_qd_des,   \
                        tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel, stiffness, damping,             \
                        effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort)
     switch (kind) {
@@ -186,6 +197,32 @@ extern "C" int mdp_actuator_pd_compute_after_update(const mdp_scene_update_t* up
 #undef LAUNCH
     MDP_LAUNCH_CHECK();
     return MDP_OK;
+}
+
+extern "C" int mdp_actuator_pd_compute_after_update(const mdp_scene_update_t* update, float dt, int kind, int num_envs,
+                                                    int num_joints, const float* q_des, int ld_q_des,
+                                                    const float* qd_des, int ld_qd_des, const float* tau_ff,
+                                                    int ld_tau_ff, const float* joint_pos, int ld_pos,
+                                                    const float* joint_vel, int ld_vel, const float* stiffness,
+                                                    const float* damping, const float* effort_limit,
+                                                    const float* velocity_limit, float saturation_effort,
+                                                    float* computed_effort, float* applied_effort, void* stream) {
+    return pd_launch(nullptr, update, dt, kind, num_envs, num_joints, q_des, ld_q_des, qd_des, ld_qd_des, tau_ff, ld_tau_ff,
+                     joint_pos, ld_pos, joint_vel, ld_vel, stiffness, damping, effort_limit, velocity_limit,
+                     saturation_effort, computed_effort, applied_effort, stream);
+}
+
+extern "C" int mdp_actuator_pd_compute_with_action(const mdp_joint_action_t* action, int kind, int num_envs,
+                                                   int num_joints, const float* qd_des, int ld_qd_des,
+                                                   const float* tau_ff, int ld_tau_ff, const float* joint_pos, int ld_pos,
+                                                   const float* joint_vel, int ld_vel, const float* stiffness,
+                                                   const float* damping, const float* effort_limit,
+                                                   const float* velocity_limit, float saturation_effort,
+                                                   float* computed_effort, float* applied_effort, void* stream) {
+    MDP_REQUIRE(action, "null joint action");
+    return pd_launch(action, nullptr, 0.0f, kind, num_envs, num_joints, action->processed, num_joints, qd_des, ld_qd_des,
+                     tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel, stiffness, damping, effort_limit,
+                     velocity_limit, saturation_effort, computed_effort, applied_effort, stream);
 }
 
 extern "C" int mdp_actuator_pd_compute(int kind, int num_envs, int num_joints,

@@ -7,6 +7,7 @@
 #include "mdp_host.hpp"
 #include "scene_update_device.hpp"
 #include "command_device.hpp"
+#include "joint_action_device.hpp"
 
 using namespace mdp;
 
@@ -189,23 +190,11 @@ __global__ void k_sensor_tick(int N, float* __restrict__ ts, const float* __rest
 }
 
 // action_manager.py:331-332 + joint_actions.py:130-139
-__global__ void k_joint_action(int64_t total, int A, const float* __restrict__ in, int ld_in,
-                               float* __restrict__ action, float* __restrict__ prev, float* __restrict__ processed,
-                               const float* __restrict__ scale_vec, float scale, const float* __restrict__ offset,
-                               const float* __restrict__ clip) {
+__global__ void k_joint_action(int64_t total, int A, mdp_joint_action_t a) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         int64_t e = i / A;
-        int a = (int)(i - e * A);
-        float raw = in[e * ld_in + a];
-        if (prev) prev[i] = action[i];
-        action[i] = raw;
-        if (processed) {
-            float sc = scale_vec ? scale_vec[a] : scale;
-            float p = raw * sc + (offset ? offset[i] : 0.0f);
-            if (clip) p = tclamp(p, clip[2 * i], clip[2 * i + 1]);
-            processed[i] = p;
-        }
+        joint_action_element(a, e, (int)(i - e * A), A, true);
     }
 }
 
@@ -359,8 +348,11 @@ extern "C" int mdp_joint_action_process(int num_envs, int action_dim, const floa
     MDP_REQUIRE(ld_in >= action_dim, "Invalid action shape, expected: %d, received: %d.", action_dim, ld_in);
     int64_t total = (int64_t)num_envs * action_dim;
     if (total == 0) return MDP_OK;
-    hipLaunchKernelGGL(k_joint_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), total, action_dim,
-                       actions_in, ld_in, action, prev_action, processed, scale_vec, scale, offset, clip);
+    mdp_joint_action_t a;
+    std::memset(&a, 0, sizeof(a));
+    a.actions_in = actions_in; a.ld_in = ld_in; a.action = action; a.prev_action = prev_action; a.processed = processed;
+    a.scale_vec = scale_vec; a.scale = scale; a.offset = offset; a.clip = clip;
+    hipLaunchKernelGGL(k_joint_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), total, action_dim, a);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

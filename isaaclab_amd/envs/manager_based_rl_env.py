@@ -32,6 +32,7 @@ class ManagerBasedRLEnv:
         self.auto_reset = auto_reset
         self.fuse_post_physics = True   # episode counter + terminations + rewards in one launch
         self.fuse_substeps = True       # scene.update(k) + write_data_to_sim(k+1) in one launch
+        self.fold_action = True         # process_action inside the first actuator launch of the step
         # last scene.update + terminations + rewards + command + observations + height-scan cast in one launch
         self.single_launch_post_physics = True
         # (terminations + rewards, command) and the height-scan cast on two streams (only without a reset in between)
@@ -98,7 +99,10 @@ class ManagerBasedRLEnv:
     # -- stepping -----------------------------------------------------------------------------------------
     def step(self, action: torch.Tensor):
         """manager_based_rl_env.py:152-241"""
-        self.action_manager.process_action(action.to(self.device))
+        # the first actuator launch of the step processes the action itself when the terms allow it
+        deferred = self.action_manager.deferred_action(action.to(self.device)) if self.fold_action else None
+        if deferred is None:
+            self.action_manager.process_action(action.to(self.device))
         decimation = self.cfg.decimation
         concurrent = (self.concurrent_post_physics and not self.auto_reset and self._can_fuse_post_physics()
                       and not self._post_physics_reads_lazy_sensor())
@@ -107,7 +111,7 @@ class ManagerBasedRLEnv:
         split = concurrent and om.can_split_sensor_terms()
         early_cast = split and self.scene.fused_update and len(om.scan_sensors()) > 0
         self.action_manager.apply_action()
-        self.scene.write_data_to_sim()
+        self.scene.write_data_to_sim(joint_action=deferred)
         for k in range(decimation):
             self.physics.advance()                      # sim.step(render=False): synthetic / replayed
             if k + 1 < decimation:

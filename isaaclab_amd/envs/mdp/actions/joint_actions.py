@@ -73,6 +73,15 @@ class JointAction(ActionTerm):
         return self._offset
 
     def _launch(self, actions: torch.Tensor, action_buf: torch.Tensor, prev_buf: torch.Tensor | None):
+        a, ld, scale_vec, scale, off = self._action_args(actions, action_buf, prev_buf)
+        L.check(L.lib.mdp_joint_action_process(self.num_envs, self.action_dim, a.data_ptr(), ld,
+                                               action_buf.data_ptr(), L.ptr(prev_buf) if prev_buf is not None else None,
+                                               self._processed_actions.data_ptr(),
+                                               L.ptr(scale_vec) if scale_vec is not None else None, float(scale),
+                                               L.ptr(off) if off is not None else None,
+                                               L.ptr(self._clip) if self._clip is not None else None, L.stream()))
+
+    def _action_args(self, actions: torch.Tensor, action_buf: torch.Tensor, prev_buf: torch.Tensor | None):
         a, ld = L.rows(actions.to(self.device), "actions")
         scale_vec = None
         scale = 1.0
@@ -83,12 +92,28 @@ class JointAction(ActionTerm):
         else:
             scale = self._scale
         off = self._offset_tensor()
-        L.check(L.lib.mdp_joint_action_process(self.num_envs, self.action_dim, a.data_ptr(), ld,
-                                               action_buf.data_ptr(), L.ptr(prev_buf) if prev_buf is not None else None,
-                                               self._processed_actions.data_ptr(),
-                                               L.ptr(scale_vec) if scale_vec is not None else None, float(scale),
-                                               L.ptr(off) if off is not None else None,
-                                               L.ptr(self._clip) if self._clip is not None else None, L.stream()))
+        return a, ld, scale_vec, scale, off
+
+    def can_fold_into_actuator(self) -> bool:
+        """Whether the first actuator launch of the step can process this term's action itself
+        (``mdp_actuator_*_compute_with_action``): a position target for every joint of an articulation whose single
+        actuator group accepts it."""
+        return False
+
+    def fill_joint_action(self, actions: torch.Tensor, action_buf: torch.Tensor, prev_buf: torch.Tensor) -> "L.MdpJointAction":
+        """The arguments of ``process_actions_fused`` as the record the actuator launch takes."""
+        a, ld, scale_vec, scale, off = self._action_args(actions, action_buf, prev_buf)
+        self._raw_actions = action_buf
+        d = L.MdpJointAction()
+        d.actions_in, d.ld_in = a.data_ptr(), ld
+        d.action, d.prev_action = action_buf.data_ptr(), prev_buf.data_ptr()
+        d.processed = self._processed_actions.data_ptr()
+        d.scale_vec = scale_vec.data_ptr() if scale_vec is not None else None
+        d.scale = float(scale)
+        d.offset = off.data_ptr() if off is not None else None
+        d.clip = self._clip.data_ptr() if self._clip is not None else None
+        self._fold_keep = (a, off, scale_vec)
+        return d
 
     def process_actions(self, actions: torch.Tensor):
         """joint_actions.py:130-139"""
@@ -113,6 +138,11 @@ class JointPositionAction(JointAction):
             # all joints: write the processed action straight into the articulation's target buffer, so
             # apply_actions() (called every physics sub-step) has nothing left to copy
             self._processed_actions = self._asset.data.joint_pos_target
+
+    def can_fold_into_actuator(self) -> bool:
+        return (self._joint_ids == slice(None) and self.action_dim == self._asset.num_joints
+                and self._processed_actions.data_ptr() == self._asset.data.joint_pos_target.data_ptr()
+                and getattr(self._asset, "can_fold_joint_action", False))
 
     def apply_actions(self):
         self._asset.set_joint_position_target(self.processed_actions, joint_ids=self._joint_ids)

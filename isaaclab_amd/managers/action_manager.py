@@ -114,6 +114,17 @@ class ActionManager(ManagerBase):
             term.process_actions(action[:, idx : idx + term.action_dim])
             idx += term.action_dim
 
+    def deferred_action(self, action: torch.Tensor):
+        """``process_action`` without its launch: returns ``(asset, MdpJointAction)`` for the caller to hand to that
+        asset's first ``write_data_to_sim`` of the step (the actuator launch then processes the action itself), or
+        ``None`` when the terms do not allow it -- the caller then calls ``process_action``."""
+        term = self._fused_term
+        if term is None or not term.can_fold_into_actuator():
+            return None
+        if self.total_action_dim != action.shape[1]:
+            raise ValueError(f"Invalid action shape, expected: {self.total_action_dim}, received: {action.shape[1]}.")
+        return term._asset, term.fill_joint_action(action, self._action, self._prev_action)
+
     def apply_action(self) -> None:
         for term in self._terms.values():
             term.apply_actions()

@@ -233,3 +233,56 @@ def test_linear_interpolation(golden, device):
     assert_close(to_np(li.compute(to_dev(G["li_q"], device))), G["li_out"])
     with pytest.raises(ValueError):       # linear_interpolation.py:38-48
         LinearInterpolation(to_dev(G["li_x"], device), to_dev(G["li_y"][:3], device), device)
+
+
+@pytest.mark.parametrize("n", (3, 517))
+def test_action_processed_inside_the_actuator_launch(device, n):
+    """mdp_actuator_pd_compute_with_action == mdp_joint_action_process followed by mdp_actuator_pd_compute, bit for
+    bit (action / prev_action / processed buffers and both effort outputs), with scale vector, offset and clip."""
+    import ctypes as C
+
+    import torch
+
+    from isaaclab_amd import _lib as L
+
+    J = 12
+    g = torch.Generator().manual_seed(n)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(device)
+    raw, q, qd = rnd(n, J + 3)[:, :J], rnd(n, J), rnd(n, J)      # strided raw actions
+    scale_vec, offset = rnd(J).abs() + 0.1, rnd(n, J)
+    clip = torch.stack([offset - 0.3, offset + 0.3], dim=-1).contiguous()
+    kp, kd = rnd(n, J).abs() * 40, rnd(n, J).abs() * 2
+    lim, vlim = torch.full((n, J), 80.0, device=device), torch.full((n, J), 7.5, device=device)
+
+    def run(fused):
+        action, prev = rnd(n, J) * 0 + 0.25, torch.zeros(n, J, device=device)
+        processed = torch.zeros(n, J, device=device)
+        computed, applied = torch.zeros(n, J, device=device), torch.zeros(n, J, device=device)
+        a = L.MdpJointAction()
+        a.actions_in, a.ld_in = raw.data_ptr(), raw.stride(0)
+        a.action, a.prev_action, a.processed = action.data_ptr(), prev.data_ptr(), processed.data_ptr()
+        a.scale_vec, a.scale, a.offset, a.clip = scale_vec.data_ptr(), 1.0, offset.data_ptr(), clip.data_ptr()
+        tail = (None, 0, None, 0, q.data_ptr(), J, qd.data_ptr(), J, kp.data_ptr(), kd.data_ptr(), lim.data_ptr(),
+                vlim.data_ptr(), 120.0, computed.data_ptr(), applied.data_ptr(), L.stream(device))
+        kind = L.ACT_KINDS["MDP_ACT_DC_MOTOR"]
+        if fused:
+            L.check(L.lib.mdp_actuator_pd_compute_with_action(C.byref(a), kind, n, J, *tail))
+        else:
+            L.check(L.lib.mdp_joint_action_process(n, J, a.actions_in, a.ld_in, a.action, a.prev_action, a.processed,
+                                                   a.scale_vec, a.scale, a.offset, a.clip, L.stream(device)))
+            L.check(L.lib.mdp_actuator_pd_compute(kind, n, J, processed.data_ptr(), J, *tail))
+        torch.cuda.synchronize()
+        return [to_np(t) for t in (action, prev, processed, computed, applied)]
+
+    for got, exp in zip(run(True), run(False)):
+        np.testing.assert_array_equal(got, exp)
+    exp_p = np.clip(to_np(raw) * to_np(scale_vec) + to_np(offset), to_np(clip)[..., 0], to_np(clip)[..., 1])
+    assert_close(run(True)[2], exp_p)
+    with pytest.raises(ValueError, match="Invalid action shape"):
+        a = L.MdpJointAction()
+        a.actions_in, a.ld_in = raw.data_ptr(), J - 1
+        a.action = a.prev_action = a.processed = q.data_ptr()
+        L.check(L.lib.mdp_actuator_pd_compute_with_action(
+            C.byref(a), L.ACT_KINDS["MDP_ACT_IDEAL_PD"], n, J, None, 0, None, 0, q.data_ptr(), J, qd.data_ptr(), J,
+            kp.data_ptr(), kd.data_ptr(), lim.data_ptr(), vlim.data_ptr(), 0.0, q.data_ptr(), q.data_ptr(),
+            L.stream(device)))

@@ -28,6 +28,7 @@ def run_env(name, n, steps, device, seed, fuse_cast=None, fused=True, persistent
         env.scene.fused_update = False
         env.fuse_post_physics = False
         env.fuse_substeps = False
+        env.fold_action = False
         env.concurrent_post_physics = False
     outs = []
     for t in range(steps):
