@@ -178,7 +178,7 @@ MDP_DEV void dc_clip_store(float tau, float qd, int64_t row, const float* __rest
 // Blocks >= nb_act carry the scene update of the frame this launch reads (see k_actuator_pd).
 template <int H>
 __global__ void __launch_bounds__(256)
-k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
+k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact, int upd_envs,
        mdp_joint_action_t jact, NetDev net, const float* __restrict__ packed, int64_t rows, int J,
        const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
        const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
@@ -190,7 +190,7 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
     // instead of behind the actuator blocks
     const unsigned nb_upd = gridDim.x - nb_act;
     if (blockIdx.x < nb_upd) {
-        scene_update_block(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact);
+        scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
         return;
     }
     const unsigned bid = blockIdx.x - nb_upd;
@@ -304,7 +304,7 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
 // order as k_lstm: bit-identical outputs.
 template <int NL>
 __global__ void __launch_bounds__(256)
-k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
+k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact, int upd_envs,
             mdp_joint_action_t jact, NetDev net, const float* __restrict__ packed, int64_t rows, int J,
             const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
             const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
@@ -316,7 +316,7 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
     const unsigned nb_upd = gridDim.x - nb_act;
     if (blockIdx.x < nb_upd) {
         MDP_STAMP(0, 1);
-        scene_update_block(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact);
+        scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
         MDP_STAMP(1);
         return;
     }
@@ -622,7 +622,7 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     MDP_REQUIRE(lds_bytes <= 150 * 1024, "network too large for LDS staging (%zu bytes)", lds_bytes);
     MDP_REQUIRE(((uintptr_t)packed_weights & 15) == 0, "packed_weights must be 16-byte aligned");
     unsigned nb_act = net_grid(rows);
-    dim3 grid(nb_act + plan.total), block(256);
+    dim3 grid(nb_act + plan.carried_total), block(256);
     hipStream_t s = as_stream(stream);
 #define LAUNCH(HH)                                                                                                 \
     do {                                                                                                           \
@@ -630,7 +630,7 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
             MDP_CHECK_HIP(hipFuncSetAttribute((const void*)k_lstm<HH>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                               (int)lds_bytes));                                                    \
         hipLaunchKernelGGL(k_lstm<HH>, grid, block, lds_bytes, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint, \
-                           plan.nb_contact, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,     \
+                           plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,     \
                            ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,      \
                            saturation_effort, computed_effort, applied_effort);                                    \
     } while (0)
@@ -639,12 +639,12 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1) {
         if (desc->lstm_layers == 1)
             hipLaunchKernelGGL(k_lstm8_reg<1>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
-                               plan.nb_contact, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                               plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
                                joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
                                saturation_effort, computed_effort, applied_effort);
         else
             hipLaunchKernelGGL(k_lstm8_reg<2>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
-                               plan.nb_contact, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                               plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
                                joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
                                saturation_effort, computed_effort, applied_effort);
         MDP_LAUNCH_CHECK();

@@ -15,7 +15,7 @@ namespace {
 // launch; nb_act == gridDim.x when there is none).
 template <int KIND>
 __global__ void __launch_bounds__(256)
-k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact,
+k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact, int upd_envs,
               mdp_joint_action_t act, int64_t total, int J,
                               const float* __restrict__ q_des, int ld_q_des,
                               const float* __restrict__ qd_des, int ld_qd_des,
@@ -27,7 +27,7 @@ k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_roo
                               float sat, float* __restrict__ computed, float* __restrict__ applied) {
     const unsigned nb_upd = gridDim.x - nb_act;   // carried scene update: the first blocks of the grid
     if (blockIdx.x < nb_upd) {
-        scene_update_block(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact);
+        scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
         return;
     }
     for (int64_t i = (blockIdx.x - nb_upd) * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -181,11 +181,11 @@ static int pd_launch(const mdp_joint_action_t* action, const mdp_scene_update_t*
     int64_t total = (int64_t)num_envs * num_joints;
     const int block = 256;
     unsigned nb_act = grid_for(total, block);
-    unsigned grid = nb_act + plan.total;
+    unsigned grid = nb_act + plan.carried_total;
     hipStream_t s = as_stream(stream);
 #define LAUNCH(K)                                                                                              \
     hipLaunchKernelGGL(k_actuator_pd<K>, dim3(grid), dim3(block), 0, s, plan.d, dt, nb_act, plan.nb_root,      \
-                       plan.nb_joint, plan.nb_contact, act, total, num_joints, q_des, ld_q_des, qd_des, ld_qd_des,   \
+                       plan.nb_joint, plan.nb_contact, plan.carried_envs, act, total, num_joints, q_des, ld_q_des, qd_des, ld_qd_des,   \
                        tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel, stiffness, damping,             \
                        effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort)
     switch (kind) {

@@ -4,6 +4,7 @@
 #pragma once
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
+#include <cstdlib>
 
 namespace mdp {
 
@@ -292,7 +293,24 @@ __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, f
 struct SceneUpdatePlan {
     mdp_scene_update_t d;
     unsigned nb_root = 0, nb_joint = 0, nb_contact = 0, nb_tick = 0, total = 0;
+    // layout of an update CARRIED by an actuator launch: carried_envs > 0 -> carried_total blocks that each run
+    // scene_update_envs over carried_envs envs (a quarter of the blocks of the role-split layout: the actuator blocks
+    // behind them start sooner); 0 -> the role-split layout above (MDP_UPD_ENVS=0)
+    int carried_envs = 0;
+    unsigned carried_total = 0;
 };
+
+// block b of the update carried by an actuator launch (see SceneUpdatePlan)
+__device__ __forceinline__ void scene_update_carried(const mdp_scene_update_t& d, float dt, unsigned b, unsigned nb_root,
+                                                     unsigned nb_joint, unsigned nb_contact, int carried_envs) {
+    if (carried_envs > 0) {
+        int64_t e0 = (int64_t)b * carried_envs;
+        int64_t e1 = e0 + carried_envs < d.num_envs ? e0 + carried_envs : d.num_envs;
+        scene_update_envs(d, dt, (int)e0, (int)e1);
+    } else {
+        scene_update_block(d, dt, b, nb_root, nb_joint, nb_contact);
+    }
+}
 
 // validates a descriptor and sizes the block ranges (host)
 inline int scene_update_plan(const mdp_scene_update_t* desc, SceneUpdatePlan* plan) {
@@ -332,6 +350,9 @@ inline int scene_update_plan(const mdp_scene_update_t* desc, SceneUpdatePlan* pl
     }
     plan->nb_tick = d.num_ticks ? blocks((int64_t)N * d.num_ticks) : 0;
     plan->total = plan->nb_root + plan->nb_joint + plan->nb_contact + plan->nb_tick;
+    static const int carried = [] { const char* v = std::getenv("MDP_UPD_ENVS"); return v ? std::atoi(v) : 8; }();  // one round of items per block
+    plan->carried_envs = carried > 0 && N > 0 ? carried : 0;
+    plan->carried_total = plan->carried_envs ? (unsigned)(((int64_t)N + plan->carried_envs - 1) / plan->carried_envs) : plan->total;
     if (!has_joint) { plan->d.joint_acc = nullptr; plan->d.joint_pos = nullptr; plan->d.joint_vel = nullptr; }
     return MDP_OK;
 }
