@@ -135,3 +135,21 @@ def test_h1_rough(device, n, fused):
     assert env.reward_manager.active_terms == [name for name, _, _ in orc.s["rewards"]]
     assert len(env.scene["robot"].actuators) == 3
     compare(outs, replay_oracle(rec, 5))
+
+
+def test_post_physics_step_rejects_what_it_does_not_cover(device):
+    """mdp_post_physics_step only takes casts that qualify for the vertical-ray kernel (grid-accelerated mesh): a BVH
+    mesh comes back as MDP_ERR_UNSUPPORTED -> NotImplementedError, and the env keeps the separate launches; missing
+    programs are a ValueError."""
+    import ctypes as C
+
+    from isaaclab_amd import _lib as L
+
+    env, rec, outs = run_env("anymal_d_rough", 16, 3, device, seed=21, small_terrain=True, persistent=True)
+    assert env.mesh.info()["accel"] == "bvh" and getattr(env, "_single_launch_steps", 0) == 0
+    env._mesh_has_grid = lambda mesh: True          # skip the host-side check: the C entry point must refuse itself
+    with pytest.raises(NotImplementedError, match="vertical-ray"):
+        env._post_physics_single_launch()
+    tr = L.MdpTerminationRewardArgs()
+    with pytest.raises(ValueError, match="programs required"):
+        L.check(L.lib.mdp_post_physics_step(16, None, 0.0, C.byref(tr), None, None, None, L.stream(device)))
