@@ -327,16 +327,22 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
     int64_t wave = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
     int64_t nwaves = (int64_t)nb_act * (blockDim.x >> 6);
     int64_t ngroups = (rows + 15) / 16;
-    float x0 = 0.0f, x1 = 0.0f;
+    float x0 = 0.0f, x1 = 0.0f, lim_r = 0.0f, vl_r = 1.0f;
     float hreg[NL][TPL], creg[NL][TPL];
     int64_t rr = 0;
     bool valid = false;
+    // every global input of a row, the limits of the final clip included, is requested in one go (rows < 2^31 here:
+    // 32-bit index arithmetic -- a 64-bit division costs more than the whole gate evaluation)
     auto load_group = [&](int64_t g) {
         int64_t row = g * 16 + col;
         valid = row < rows;
         rr = valid ? row : rows - 1;
-        int64_t e = rr / J;
-        int j = (int)(rr - e * J);
+        const unsigned ur = (unsigned)rr;
+        const unsigned ue = ur / (unsigned)J;
+        int64_t e = ue;
+        int j = (int)(ur - ue * (unsigned)J);
+        lim_r = eff_lim[rr];
+        vl_r = vel_lim[rr];
         // actuator_net.py:80-81 (jact.actions_in: this launch also processes the action of the step)
         float des = jact.actions_in ? joint_action_element(jact, e, j, J, valid && gq == 0) : q_des[e * ld_q_des + j];
         x0 = des - q[e * ld_q + j];
@@ -370,7 +376,7 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
     for (int r = 0; r < 4; ++r) bm[r] = packed[net.L.mlp_b[0] + r * 64 + lane];
     const int act = net.d.mlp_act[0];
     while (g < ngroups) {
-        const float cx0 = x0, cx1 = x1;
+        const float cx0 = x0, cx1 = x1, clim = lim_r, cvl = vl_r;
         const bool cvalid = valid;
         const int64_t crr = rr;
         float hl[NL][TPL], cl[NL][TPL];
@@ -422,7 +428,13 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
 #pragma unroll
         for (int s = 0; s < TPL; ++s) acc = mfma4(wm[s], prev[s], acc);
         float tau = act_fn(acc[0], act);
-        if (cvalid && gq == 0) dc_clip_store(tau, cx1, crr, eff_lim, vel_lim, sat, computed, applied);
+        if (cvalid && gq == 0) {
+            // dc_clip_store with the limits already in registers
+            float mx = tclamp(sat * (1.0f - cx1 / cvl), 0.0f, clim);
+            float mn = tclamp(sat * (-1.0f - cx1 / cvl), -clim, 0.0f);
+            computed[crr] = tau;
+            applied[crr] = tclamp(tau, mn, mx);
+        }
         g = gnext;
     }
     MDP_STAMP(1);
@@ -636,7 +648,7 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     } while (0)
     // register-resident weights for the ANYdrive shape (MDP_LSTM_GENERIC=1 forces the LDS kernel: parity tests)
     static const bool force_generic = [] { const char* e = std::getenv("MDP_LSTM_GENERIC"); return e && e[0] == '1'; }();
-    if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1) {
+    if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1 && rows < (1ll << 31)) {
         if (desc->lstm_layers == 1)
             hipLaunchKernelGGL(k_lstm8_reg<1>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
                                plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
