@@ -109,6 +109,11 @@ def algorithmic_bytes(env) -> dict:
     return table
 
 
+def _trace(rank, msg):
+    if os.environ.get("MDP_BENCH_TRACE") == "1":
+        print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
@@ -116,15 +121,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (MI355X); there is no CPU path")
+    # rehearsal of the N > 1 path on a one-GPU box (never used by the driver): every rank on cuda:0, gloo transport
+    rehearsal = os.environ.get("MDP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(device))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(device))
     from isaaclab_amd.distributed import EpisodeStats
     from isaaclab_amd.envs.synthetic import make_velocity_env
 
+    _trace(rank, "process group up")
     torch.manual_seed(1234 + rank)
     ring = args.ring
     env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
@@ -147,6 +160,7 @@ def main():
     warm = (warm + ring - 1) // ring * ring       # keep the frame cursor aligned with the ring
     eager_steps(0, warm)
     torch.cuda.synchronize()
+    _trace(rank, "warm-up done")
 
     graph = None
     if not args.no_graph:
@@ -168,6 +182,8 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
+    reduce_stats = stats.reduce if os.environ.get("MDP_BENCH_SYNC_STATS") == "1" else stats.reduce_async
+
     def run(k_steps):
         done, next_stats = 0, args.stats_every
         while done < k_steps:
@@ -178,9 +194,9 @@ def main():
                 env.step(actions[done % ring])
                 done += 1
             if done >= next_stats:          # end of a rollout: merge the episode statistics across ranks
-                stats.reduce_async()
+                reduce_stats()
                 next_stats += args.stats_every
-        stats.reduce_async()
+        reduce_stats()
 
     def barrier():
         if world > 1:
@@ -189,13 +205,18 @@ def main():
             dist.barrier()
 
     K = args.steps
+    _trace(rank, f"graph {'captured' if graph is not None else 'unavailable'}")
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(K)
+    _trace(rank, "steps enqueued")
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    _trace(rank, "timed region done")
+    episode_stats = stats.result()      # drains the statistics collectives before anything is captured again
+    _trace(rank, f"episode statistics merged ({len(episode_stats)} entries)")
     if world > 1:
         import torch.distributed as dist
 

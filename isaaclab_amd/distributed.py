@@ -102,6 +102,17 @@ class EpisodeStats:
         self._work = None
         self._ready = torch.cuda.Event() if self._stream is not None else None
 
+    def reduce(self, mask: torch.Tensor | None = None):
+        """Per-rank partial sums and one all-reduce(sum) of the packed vector, in order on the current stream."""
+        off = 0
+        for src, rows in self._sources:
+            L.check(L.lib.mdp_stats_masked_sums(src.data_ptr(), rows, self.env.num_envs, L.ptr(mask),
+                                                self.payload[off:].data_ptr(), L.stream(self.device)))
+            off += 2 * rows
+        work = allreduce_payload(self.payload, self.world, self.group)
+        if work is not None:
+            work.wait()
+
     def reduce_async(self, mask: torch.Tensor | None = None):
         """Per-rank partial sums on a side stream, then one all-reduce(sum) of the packed vector."""
         cur = torch.cuda.current_stream(self.device)
@@ -114,6 +125,10 @@ class EpisodeStats:
                                                     self.payload[off:].data_ptr(), self._stream.cuda_stream))
                 off += 2 * rows
             self._work = allreduce_payload(self.payload, self.world, self.group)
+            if self._work is not None:
+                # device-side wait (RCCL: the side stream waits for the collective's stream, the host does not block):
+                # the next rollout's partial sums must not overwrite the payload while it is being reduced
+                self._work.wait()
 
     def result(self) -> dict[str, float]:
         if self._work is not None:
@@ -128,6 +143,13 @@ def allreduce_payload(payload: torch.Tensor, world: int, group=None):
     """One asynchronous all-reduce(sum) of the packed ``[sum, count]`` vector; returns the work handle (None when
     there is a single rank)."""
     if world > 1:
+        if payload.is_cuda and dist.get_backend(group) == "gloo":
+            # gloo is the CPU transport (tests, one-box rehearsals): its device-tensor path never completes next to
+            # hipGraph replays on this stack, so stage through the host -- RCCL ("nccl") takes the branch below
+            host = payload.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            payload.copy_(host)
+            return None
         return dist.all_reduce(payload, op=dist.ReduceOp.SUM, group=group, async_op=True)
     return None
 
