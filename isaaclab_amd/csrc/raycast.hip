@@ -257,6 +257,7 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     }
     // ---- cell records: per cell sorted by descending zmax (ties: ascending face id), 12 floats each
     std::vector<float> recs;
+    std::vector<uint8_t> disjoint;
     {
         const size_t ncell = (size_t)ncx * ncy;
         std::vector<float> zmax_of((size_t)num_tris), zmin_of((size_t)num_tris);
@@ -271,6 +272,68 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
                 std::sort(b, e, [&](int32_t x, int32_t y) {
                     return zmax_of[x] > zmax_of[y] || (zmax_of[x] == zmax_of[y] && x < y);
                 });
+        }
+        // ---- cells whose triangles have pairwise disjoint xy interiors (every cell of a height field away from its
+        // vertical walls): a vertical ray strictly inside one triangle's footprint cannot touch another one, so the
+        // walk may stop there (raycast_device.hpp: MDP_RC_CELL_DISJOINT).  Such a cell is ordered by how much of the
+        // cell each triangle covers (most likely hit first); the zmax order is only needed by the zmax early exit,
+        // which these cells do not use.
+        disjoint.assign(ncell, 0);
+        auto orient = [&](const float* t, int i, int j, double px, double py) {
+            double ax = t[3 * i], ay = t[3 * i + 1], bx = t[3 * j], by = t[3 * j + 1];
+            return (bx - ax) * (py - ay) - (by - ay) * (px - ax);   // exact sign for float inputs
+        };
+        auto separated_by_edge_of = [&](const float* A, const float* B) {
+            double area = orient(A, 0, 1, A[6], A[7]);
+            if (area == 0.0) return false;
+            for (int i = 0; i < 3; ++i) {
+                int j = (i + 1) % 3;
+                bool all_out = true;
+                for (int k = 0; k < 3 && all_out; ++k) {
+                    double o = orient(A, i, j, B[3 * k], B[3 * k + 1]);
+                    all_out = area > 0.0 ? o <= 0.0 : o >= 0.0;
+                }
+                if (all_out) return true;
+            }
+            return false;
+        };
+        std::vector<std::pair<int, int32_t>> scored;
+        for (size_t c = 0; c < ncell; ++c) {
+            int32_t* b = m->h_cell_tris.data() + counts[c];
+            const int n = counts[c + 1] - counts[c];
+            if (n < 1 || n > 16) continue;
+            bool ok = true;
+            for (int i = 0; i < n && ok; ++i) {
+                const float* A = tv.data() + 9 * (size_t)b[i];
+                if (orient(A, 0, 1, A[6], A[7]) == 0.0) ok = false;      // projects to a segment (vertical wall)
+                for (int j = i + 1; j < n && ok; ++j) {
+                    const float* B = tv.data() + 9 * (size_t)b[j];
+                    ok = separated_by_edge_of(A, B) || separated_by_edge_of(B, A);
+                }
+            }
+            if (!ok) continue;
+            disjoint[c] = 1;
+            if (n < 2) continue;
+            // coverage score: how many of 4 x 4 sample points of the cell fall inside the triangle
+            const int cx = (int)(c % (size_t)ncx), cy = (int)(c / (size_t)ncx);
+            scored.clear();
+            for (int i = 0; i < n; ++i) {
+                const float* A = tv.data() + 9 * (size_t)b[i];
+                double area = orient(A, 0, 1, A[6], A[7]);
+                int score = 0;
+                for (int sy = 0; sy < 4; ++sy)
+                    for (int sx = 0; sx < 4; ++sx) {
+                        double px = (double)gx0 + (double)cellf * (cx + (sx + 0.5) * 0.25);
+                        double py = (double)gy0 + (double)cellf * (cy + (sy + 0.5) * 0.25);
+                        double o0 = orient(A, 0, 1, px, py), o1 = orient(A, 1, 2, px, py), o2 = orient(A, 2, 0, px, py);
+                        bool in = area > 0.0 ? (o0 >= 0 && o1 >= 0 && o2 >= 0) : (o0 <= 0 && o1 <= 0 && o2 <= 0);
+                        score += in ? 1 : 0;
+                    }
+                scored.emplace_back(-score, b[i]);
+            }
+            // stable: equal coverage keeps the zmax / face-id order
+            std::stable_sort(scored.begin(), scored.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+            for (int i = 0; i < n; ++i) b[i] = scored[i].second;
         }
         recs.resize(m->h_cell_tris.size() * 12);
         for (size_t k = 0; k < m->h_cell_tris.size(); ++k) {
@@ -311,6 +374,8 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     int rc;
     float* d_tv = nullptr; int32_t* d_cs = nullptr; int32_t* d_ct = nullptr; float* d_nodes = nullptr; int32_t* d_bt = nullptr;
     float* d_recs = nullptr;
+    for (size_t c = 0; c < disjoint.size(); ++c)
+        if (disjoint[c]) counts[c] |= (int32_t)MDP_RC_CELL_DISJOINT;
     if ((rc = upload(tv, &d_tv, &bytes)) || (rc = upload(counts, &d_cs, &bytes)) || (rc = upload(recs, &d_recs, &bytes)) ||
         (rc = upload(m->h_cell_tris, &d_ct, &bytes)) || (rc = upload(bb.nodes, &d_nodes, &bytes)) ||
         (rc = upload(bb.order, &d_bt, &bytes))) {

@@ -49,6 +49,14 @@ typedef struct {
     int32_t face;
 } mdp_hit_t;
 
+// Top bit of a cell_start entry (device builder only; the entry's low 31 bits are the CSR offset): the triangles of the
+// cell have pairwise disjoint xy interiors and none projects to a segment.  A VERTICAL ray strictly inside one
+// footprint of such a cell cannot touch any other triangle of the cell, so its walk ends there whatever the record
+// order; the records of such a cell are ordered by coverage of the cell, NOT by zmax, so the zmax early exit must not
+// be used in it (a per-record skip is still valid).
+#define MDP_RC_CELL_DISJOINT 0x80000000u
+#define MDP_RC_CELL_OFFSET(x) ((int32_t)((uint32_t)(x) & 0x7fffffffu))
+
 MDP_RC_FN int mdp_rc_max_dim(float ax, float ay, float az) {
     // index of the largest component (first wins on ties, like a chain of > comparisons)
     int k = 0;
@@ -171,9 +179,10 @@ MDP_RC_FN void mdp_rc_consider_rec(const mdp_ray_t* r, const mdp_rec_t* rec, mdp
 #endif
 // All records of one cell.  Loads are issued MDP_RC_BATCH records at a time (independent of the running best hit)
 // so a lane has 12 x 128-bit loads in flight instead of one dependent round trip per triangle.
-MDP_RC_FN void mdp_rc_cell_recs(const mdp_mesh_view_t* m, const mdp_ray_t* r, int32_t b, int32_t e, mdp_hit_t* best) {
-    // records are sorted by descending zmax: on a downward ray a triangle lying entirely below the current best
-    // hit needs a strictly larger t, and so does every record after it
+MDP_RC_FN void mdp_rc_cell_recs(const mdp_mesh_view_t* m, const mdp_ray_t* r, int32_t b, int32_t e, int zsorted,
+                                mdp_hit_t* best) {
+    // records are sorted by descending zmax (zsorted): on a downward ray a triangle lying entirely below the current
+    // best hit needs a strictly larger t, and so does every record after it; without the order it is only skipped
     const int down = r->dz < 0.0f;
     const float inv_dz = down ? 1.0f / r->dz : 0.0f;
     int stop = 0;
@@ -187,7 +196,7 @@ MDP_RC_FN void mdp_rc_cell_recs(const mdp_mesh_view_t* m, const mdp_ray_t* r, in
             if (k + i >= e || stop) continue;
             if (down && best->face >= 0) {
                 float t_reach = (R[i].v[10] - r->oz) * inv_dz;  // parameter at which the ray reaches zmax
-                if (t_reach > best->t + (fabsf(best->t) * 1e-5f + 1e-6f)) { stop = 1; continue; }
+                if (t_reach > best->t + (fabsf(best->t) * 1e-5f + 1e-6f)) { stop = zsorted; continue; }
             }
             mdp_rc_consider_rec(r, &R[i], best);
         }
@@ -248,9 +257,10 @@ MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, fl
     if (sy != 0) { float ty = fabsf(m->cell / dy); if (ty < tstep) tstep = ty; }
     for (;;) {
         int32_t c = cy * m->ncx + cx;
-        int32_t b = m->cell_start[c], e = m->cell_start[c + 1];
+        int32_t braw = m->cell_start[c];
+        int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
         if (m->cell_recs) {
-            mdp_rc_cell_recs(m, r, b, e, &best);
+            mdp_rc_cell_recs(m, r, b, e, braw >= 0, &best);
         } else {
             for (int32_t k = b; k < e; ++k) mdp_rc_consider(r, m->tri_verts, m->cell_tris[k], &best);
         }
@@ -339,7 +349,9 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, 
     if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
     if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
     int32_t c = cy * m->ncx + cx;
-    int32_t b = m->cell_start[c], e = m->cell_start[c + 1];
+    const int32_t braw = m->cell_start[c];
+    const int disjoint = braw < 0;
+    int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
     const float inv_dz = 1.0f / r->dz;
     int stop = 0;
     for (int32_t k = b; k < e && !stop; k += BATCH) {
@@ -354,7 +366,7 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, 
             if (k + i >= e || stop) continue;
             if (best.face >= 0) {
                 float t_reach = (R[i].v[10] - r->oz) * inv_dz;
-                if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = 1; continue; }
+                if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = !disjoint; continue; }
             }
             int32_t f = mdp_rc_rec_face(&R[i]);
             float t;
@@ -377,7 +389,7 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, 
 // Same records, same order, same early exit, same t as mdp_rc_grid_down / mdp_rc_grid (the CPU oracle's path).
 template <int BATCH>
 __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_t* m, float ox, float oy, float oz, float dz,
-                                                            float max_t) {
+                                                            float max_t, int* dbg_iters = nullptr) {
     mdp_hit_t best; best.t = max_t; best.face = -1;
     float pad = 1e-3f * m->cell + 1e-6f;
     float hix = m->gx0 + m->cell * (float)m->ncx, hiy = m->gy0 + m->cell * (float)m->ncy;
@@ -388,10 +400,14 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
     if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
     if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
     int32_t c = cy * m->ncx + cx;
-    int32_t b = m->cell_start[c], e = m->cell_start[c + 1];
+    const int32_t braw = m->cell_start[c];
+    const bool disjoint = braw < 0;
+    int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
     const float Sz = 1.0f / dz;
     int stop = 0;
+    if (dbg_iters) *dbg_iters = (disjoint ? 1000 : 0) + (e - b) * 10;
     for (int32_t k = b; k < e && !stop; k += BATCH) {
+        if (dbg_iters) *dbg_iters += 1;
         mdp_rec_t R[BATCH];
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
@@ -404,7 +420,7 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
             const float* tv = R[i].v;
             if (best.face >= 0) {
                 float t_reach = (tv[10] - oz) * Sz;
-                if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = 1; continue; }
+                if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = !disjoint; continue; }
             }
             float Ax = tv[1] - oy, Ay = tv[0] - ox;
             float Bx = tv[4] - oy, By = tv[3] - ox;
@@ -421,6 +437,8 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
                 W = (float)(BxAy - ByAx);
             }
             if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) continue;
+            // strictly inside this footprint, in a cell of disjoint footprints: no other record can be touched
+            if (disjoint && ((U > 0.0f && V > 0.0f && W > 0.0f) || (U < 0.0f && V < 0.0f && W < 0.0f))) stop = 1;
             float det = (U + V) + W;
             if (det == 0.0f) continue;
             float Az = Sz * (tv[2] - oz), Bz = Sz * (tv[5] - oz), Cz = Sz * (tv[8] - oz);
