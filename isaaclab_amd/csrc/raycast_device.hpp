@@ -405,6 +405,7 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
     int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
     const float Sz = 1.0f / dz;
     int stop = 0;
+    // diagnostic (stamp build only): 1000 * disjoint + 10 * records in the cell + batches read
     if (dbg_iters) *dbg_iters = (disjoint ? 1000 : 0) + (e - b) * 10;
     for (int32_t k = b; k < e && !stop; k += BATCH) {
         if (dbg_iters) *dbg_iters += 1;

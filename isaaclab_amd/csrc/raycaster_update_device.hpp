@@ -106,7 +106,13 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
                 V3 d = ld3(dirs_l + 3 * r);
                 mdp_hit_t h;
                 if (mesh.finite) {
+#ifdef MDP_STAMPS
+                    int walk = 0;   // diagnostic: records in the cell / batches read by this ray (tools/kernel_stamps.py)
+                    h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &walk);
+                    if (g_stamps) g_stamps[8192 * 8 + (size_t)e * R + r] = (unsigned long long)walk;
+#else
                     h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist);
+#endif
                 } else {
                     mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
                     h = mdp_rc_grid_down<BATCH>(&mesh, &ray, a.max_dist);

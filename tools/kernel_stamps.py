@@ -61,7 +61,8 @@ def main():
         env.step(acts[k % acts.shape[0]])
     env.scene.sensors["height_scanner"].cfg.update_period = 0.0
     torch.cuda.synchronize()
-    buf = torch.zeros((8192, 8), dtype=torch.int64, device="cuda:0")
+    full = torch.zeros((8192 * 8 + 4096 * 187,), dtype=torch.int64, device="cuda:0")   # stamps | per-ray walk words
+    buf = full[: 8192 * 8].view(8192, 8)
     for setter in ("mdp_debug_stamps_programs", "mdp_debug_stamps_actuator_nets"):
         fn = getattr(L.lib, setter)
         fn.argtypes = [C.c_void_p]
@@ -75,6 +76,13 @@ def main():
         if rep == 2:
             show("k_post_physics", buf, {2: "managers", 1: "cast"}, {2: 5, 1: 1})
             cast_phases(buf)
+            it = full[8192 * 8:].cpu().numpy().reshape(4096, 187)
+            dis, n, batches = it // 1000, (it % 1000) // 10, it % 10
+            print("           rays in disjoint cells %.3f; records per cell mean %.2f; batches per ray mean %.2f  hist %s"
+                  % (dis.mean(), n.mean(), batches.mean(), np.bincount(batches.ravel(), minlength=8)[:8].tolist()))
+            print("           batches per ray, disjoint cells %.2f, other cells %.2f; max over each 64-ray wave: mean %.2f"
+                  % (batches[dis == 1].mean(), batches[dis == 0].mean(),
+                     np.mean([batches[:, w:w + 64].max(axis=1).mean() for w in (0, 64, 128)])))
     for rep in range(3):
         buf.zero_()
         torch.cuda.synchronize()
