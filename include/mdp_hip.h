@@ -594,10 +594,10 @@ int mdp_actuator_pd_compute_with_action(const mdp_joint_action_t* action, int ki
  *   episode_length_buf += 1; terminations; rewards            -> mdp_termination_reward_compute
  *   command_manager.compute(step_dt)                          -> mdp_velocity_command_compute (command, may be NULL)
  *   observation_manager.compute() incl. the lazy ray cast     -> mdp_obs_compute + mdp_raycaster_update (+ scan)
- * Every stage is independent per env, so a block of the launch owns 64 envs and walks them through the stages in the
+ * Every stage is independent per env, so a block of the launch owns a few envs (24) and walks them through the stages in the
  * reference order (block barriers in between), while other blocks of the same launch cast the height-scan rays (the cast
  * only needs the physics transforms: pose_xyzw + tick_dt as in mdp_raycaster_update).  Outputs are bit-identical to the
- * separate calls.  Restrictions (MDP_ERR_UNSUPPORTED otherwise; callers fall back to the separate calls): the cast must
+ * separate calls (generated noise and command samples use their own device-side epoch counters).  Restrictions (MDP_ERR_UNSUPPORTED otherwise; callers fall back to the separate calls): the cast must
  * qualify for the vertical-ray kernel (yaw-only attachment, pattern_vertical_down, grid-accelerated mesh), a single
  * command term, no lazily evaluated sensor read by a termination / reward term.  The structs only bundle the arguments
  * of the calls named above. */
