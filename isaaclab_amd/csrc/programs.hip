@@ -1063,7 +1063,7 @@ extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* upd
             ra.scan = *sc;
             if (!generated) ra.scan.rng = nullptr;
         }
-        a.cast_epb = cast->num_rays >= threads ? 1 : threads / cast->num_rays;
+        a.cast_epb = cast->num_rays >= threads ? 1 : std::min(threads / cast->num_rays, (int)RCU_MAX_EPB);
         a.cast_slot_w = cast->num_rays >= threads ? threads : cast->num_rays;
         a.nb_cast = (unsigned)std::min<int64_t>(((int64_t)num_envs + a.cast_epb - 1) / a.cast_epb, 1 << 20);
     }

@@ -594,7 +594,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     MDP_REQUIRE(!(tick_dt > 0.0f) || (timestamp && timestamp_last_update && is_outdated),
                 "tick_dt needs timestamp, timestamp_last_update and is_outdated");
     if (num_envs == 0 || num_rays == 0) return MDP_OK;
-    int epb = num_rays >= 256 ? 1 : 256 / num_rays;
+    int epb = num_rays >= 256 ? 1 : 256 / num_rays;   // <= RCU_MAX_EPB (256) env slots of the vertical-ray routine
     int slot_w = num_rays >= 256 ? 256 : num_rays;
     int threads = ((epb * slot_w + 63) / 64) * 64;
     int64_t blocks = ((int64_t)num_envs + epb - 1) / epb;
