@@ -43,16 +43,23 @@ def slice_recording(rec, ids):
     return sub
 
 
-@pytest.mark.parametrize("name,n", (("anymal_d_rough", 4096), ("anymal_c_rough", 16384)))
-def test_full_size_slice_vs_oracle_and_properties(device, name, n):
-    """configs[1] (Rough Anymal-D, 4096 envs, 765,952 rays per cast) and configs[2] (Anymal-C LSTM, 16384 envs)."""
+@pytest.mark.parametrize("name,n,fast", (("anymal_d_rough", 4096, False), ("anymal_c_rough", 16384, False),
+                                         ("anymal_c_rough", 4096, True), ("anymal_d_rough", 16384, True),
+                                         ("h1_rough", 8192, False)))
+def test_full_size_slice_vs_oracle_and_properties(device, name, n, fast):
+    """configs[1] (Rough Anymal-D, 4096 envs, 765,952 rays per cast), configs[2] (Anymal-C LSTM, 16384 envs) and the
+    per-GPU share of configs[3] (H1, three implicit actuator groups).  ``fast``: grid-accelerated mesh + persistent
+    observation buffers, i.e. the five-launch step of the benchmark (action folded into the first actuator launch,
+    carried scene updates, one post-physics launch) instead of the per-call launches."""
     import torch
 
     from isaaclab_amd.envs.synthetic import make_velocity_env
     from oracle.harness import replay_oracle
 
     steps = 3
-    env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=21, small_terrain=True)
+    env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=21, small_terrain=True,
+                                 mesh_accel="grid" if fast else "auto")
+    env.observation_manager.persistent_output = fast
     outs, rewards = [], torch.zeros(n, device=device)
     for t in range(steps):
         rec.feed(t)
@@ -60,6 +67,7 @@ def test_full_size_slice_vs_oracle_and_properties(device, name, n):
         rewards += rew
         outs.append((to_np(obs["policy"]), to_np(rew), to_np(term), to_np(trunc)))
         np.testing.assert_array_equal(to_np(env.reset_buf), outs[-1][2] | outs[-1][3])
+    assert getattr(env, "_single_launch_steps", 0) == (steps - 1 if fast else 0)
     # (a) a strided slice + the last envs, replayed by the oracle
     ids = sorted(set(range(0, n, n // 96)) | set(range(n - 17, n)))
     ref = replay_oracle(slice_recording(rec, ids), steps)
