@@ -172,7 +172,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # thread_local: helper threads of the process group (watchdog, transport) may touch the runtime meanwhile
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 eager_steps(0, ring)
             graph.replay()
             torch.cuda.synchronize()
@@ -262,7 +263,7 @@ def _graph_time(fn, reps: int = 20, replays: int = 10) -> float:
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
         for _ in range(reps):
             fn()
     g.replay()
