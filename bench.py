@@ -51,6 +51,8 @@ def parse():
     p.add_argument("--stats-every", type=int, default=24, help="rollout length between episode-stat all-reduces")
     p.add_argument("--small-terrain", action="store_true")
     p.add_argument("--fuse-cast", action="store_true", help="cast the height scan inside the observation kernel")
+    p.add_argument("--auto-reset", choices=("off", "masked"), default="off",
+                   help="masked: every step also resets its done envs without a host sync (not the headline metric)")
     return p.parse_args()
 
 
@@ -143,6 +145,8 @@ def main():
     env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
                                  small_terrain=args.small_terrain, inject_random=False)
     env.observation_manager.persistent_output = True
+    if args.auto_reset == "masked":
+        env.auto_reset = "masked"
     if "height_scanner" in env.scene.sensors:
         env.scene.sensors["height_scanner"].fuse_into_observations = args.fuse_cast
     # episode_length_buf ~ U{0..999}

@@ -569,6 +569,24 @@ int mdp_stats_moments(const float* x, int num_envs, int dim, int ld, double* out
 int mdp_stats_masked_sums(const float* values, int rows, int num_envs, const uint8_t* mask, double* out,
                           void* stream);
 
+/* Reset of per-env state by MASK instead of by id list, many buffers in ONE launch (the `buf[env_ids] = value` lines of
+ * ManagerBasedRLEnv._reset_idx's callees: sensor_base.py:192-195, contact_sensor.py:143-155, action_manager.py reset,
+ * reward_manager.py:121, command_manager.py:137-142, actuator_net.py:61-64, manager_based_rl_env.py:391).  With the
+ * mask = the step's reset_buf no `nonzero()` host sync is needed and the reset can sit inside a captured hipGraph.
+ * Each record describes `count` elements per env of `elem_bytes` (1, 4 or 8) bytes: element k of env e is at
+ * ptr + (e * env_stride + k * elem_stride) * elem_bytes -- (N, count) buffers have env_stride = count, elem_stride = 1;
+ * term-major (count, N) blocks env_stride = 1, elem_stride = N.  value_bits holds the fill value's bit pattern. */
+typedef struct {
+    void* ptr;
+    int32_t elem_bytes;
+    int32_t count;
+    int64_t env_stride;
+    int64_t elem_stride;
+    uint64_t value_bits;
+} mdp_fill_t;
+#define MDP_MAX_FILLS 48
+int mdp_masked_fill(const mdp_fill_t* fills, int num_fills, const uint8_t* env_mask, int num_envs, void* stream);
+
 /* ManagerBasedRLEnv.step lines 168-186 for a joint-position action term that drives every joint of an articulation with
  * one actuator group: action_manager.process_action(action) (mdp_joint_action_process), apply_action() (the processed
  * action IS the joint position target) and the first scene.write_data_to_sim() of the step

@@ -136,6 +136,15 @@ class MdpJointAction(C.Structure):
     ]
 
 
+class MdpFill(C.Structure):
+    """Mirror of ``mdp_fill_t``."""
+
+    _fields_ = [
+        ("ptr", C.c_void_p), ("elem_bytes", C.c_int32), ("count", C.c_int32), ("env_stride", C.c_int64),
+        ("elem_stride", C.c_int64), ("value_bits", C.c_uint64),
+    ]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -63,7 +63,47 @@ __global__ void k_masked_sums(const float* __restrict__ v, int rows, int N, cons
     if (threadIdx.x == 0) { out[2 * k] = rs[0]; out[2 * k + 1] = rc[0]; }
 }
 
+struct FillTable { mdp_fill_t f[MDP_MAX_FILLS]; };
+
+// one blockIdx.y per buffer; x covers (env, element) pairs, elements fastest for (N, count) buffers
+__global__ void k_masked_fill(FillTable t, const uint8_t* __restrict__ mask, int N) {
+    const mdp_fill_t f = t.f[blockIdx.y];
+    const int64_t total = (int64_t)N * f.count;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t e, k;
+        if (f.env_stride == 1) { k = i / N; e = i - k * N; }       // term-major: envs fastest
+        else { e = i / f.count; k = i - e * f.count; }
+        if (!mask[e]) continue;
+        const int64_t at = e * f.env_stride + k * f.elem_stride;
+        if (f.elem_bytes == 4) reinterpret_cast<uint32_t*>(f.ptr)[at] = (uint32_t)f.value_bits;
+        else if (f.elem_bytes == 8) reinterpret_cast<uint64_t*>(f.ptr)[at] = f.value_bits;
+        else reinterpret_cast<uint8_t*>(f.ptr)[at] = (uint8_t)f.value_bits;
+    }
+}
+
 }  // namespace
+
+extern "C" int mdp_masked_fill(const mdp_fill_t* fills, int num_fills, const uint8_t* env_mask, int num_envs, void* stream) {
+    MDP_REQUIRE(num_fills >= 0 && num_fills <= MDP_MAX_FILLS, "at most %d buffers per call (got %d)", MDP_MAX_FILLS, num_fills);
+    MDP_REQUIRE(num_envs >= 0, "negative num_envs");
+    if (num_fills == 0 || num_envs == 0) return MDP_OK;
+    MDP_REQUIRE(fills && env_mask, "null pointer");
+    FillTable t;
+    std::memset(&t, 0, sizeof(t));
+    int64_t largest = 0;
+    for (int i = 0; i < num_fills; ++i) {
+        const mdp_fill_t& f = fills[i];
+        MDP_REQUIRE(f.ptr && f.count >= 0, "fill %d: null pointer or negative count", i);
+        MDP_REQUIRE(f.elem_bytes == 1 || f.elem_bytes == 4 || f.elem_bytes == 8, "fill %d: elem_bytes %d", i, f.elem_bytes);
+        t.f[i] = f;
+        largest = std::max<int64_t>(largest, (int64_t)num_envs * f.count);
+    }
+    if (largest == 0) return MDP_OK;
+    unsigned gx = (unsigned)std::min<int64_t>((largest + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_masked_fill, dim3(gx, (unsigned)num_fills), dim3(256), 0, as_stream(stream), t, env_mask, num_envs);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
 
 extern "C" int mdp_stats_moments(const float* x, int num_envs, int dim, int ld, double* out, void* stream) {
     MDP_REQUIRE(x && out, "null pointer");

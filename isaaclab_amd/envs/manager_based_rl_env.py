@@ -165,7 +165,9 @@ class ManagerBasedRLEnv:
                 self.episode_length_buf += 1
                 self.reset_buf = self.termination_manager.compute()
                 self.reward_buf = self.reward_manager.compute(dt=self.step_dt)
-            if self.auto_reset:
+            if self.auto_reset == "masked":
+                self._reset_masked(self.reset_buf)
+            elif self.auto_reset:
                 reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
                 if len(reset_env_ids) > 0:
                     self._reset_idx(reset_env_ids)
@@ -255,6 +257,126 @@ class ManagerBasedRLEnv:
             rm._step_reward.data_ptr(), L.stream(self.device)))
         self.reset_buf = tm._dones_buf
         self.reward_buf = rm._reward_buf
+
+    # -- reset by mask (the reset path without its host syncs) ------------------------------
+    def _masked_reset_plan(self):
+        """The per-env state ``_reset_idx`` zeroes, as ``mdp_fill_t`` records (built once).  Raises
+        ``NotImplementedError`` for state this path does not know how to reset."""
+        import ctypes as C
+        import struct
+
+        from .. import _lib as L
+        from ..envs.mdp.commands.velocity_command import UniformVelocityCommand
+
+        fills, keep = [], []
+
+        def add(t: torch.Tensor, count: int, env_stride: int, elem_stride: int = 1, value=0):
+            f = L.MdpFill()
+            f.ptr, f.elem_bytes, f.count = t.data_ptr(), t.element_size(), int(count)
+            f.env_stride, f.elem_stride = int(env_stride), int(elem_stride)
+            if t.dtype == torch.float32:
+                f.value_bits = struct.unpack("<I", struct.pack("<f", float(value)))[0]
+            else:
+                f.value_bits = int(value)
+            fills.append(f)
+            keep.append(t)
+
+        def add_rows(t: torch.Tensor, value=0):          # (N, ...) contiguous
+            if not t.is_contiguous() or t.shape[0] != self.num_envs:
+                raise NotImplementedError("masked reset needs contiguous (N, ...) buffers")
+            per_env = t.numel() // max(self.num_envs, 1)
+            add(t, per_env, per_env, 1, value)
+
+        n = self.num_envs
+        # scene.reset (articulation.py:163-167, sensor_base.py:182-195, contact_sensor.py:136-155, ray_caster.py:106-113)
+        for art in self.scene.articulations.values():
+            for act in art.actuators.values():
+                if hasattr(act, "sea_hidden_state"):
+                    layers, rows, hidden = act.sea_hidden_state.shape
+                    per_env = (rows // n) * hidden
+                    for state in (act.sea_hidden_state, act.sea_cell_state):
+                        for l in range(layers):
+                            add(state[l], per_env, per_env)
+                elif type(act).__name__ in ("ImplicitActuator", "IdealPDActuator", "DCMotor"):
+                    pass                                      # stateless
+                else:
+                    raise NotImplementedError(f"masked reset of actuator {type(act).__name__}")
+        for sensor in self.scene.sensors.values():
+            add_rows(sensor._timestamp)
+            add_rows(sensor._timestamp_last_update)
+            add_rows(sensor._is_outdated, 1)
+            if isinstance(sensor, ContactSensor):
+                d = sensor.data
+                add_rows(d.net_forces_w)
+                if d.net_forces_w_history.data_ptr() != d.net_forces_w.data_ptr():
+                    add_rows(d.net_forces_w_history)
+                if getattr(d, "current_air_time", None) is not None:
+                    for t in (d.current_air_time, d.last_air_time, d.current_contact_time, d.last_contact_time):
+                        add_rows(t)
+            elif isinstance(sensor, RayCaster):
+                if tuple(sensor.cfg.drift_range) != (0.0, 0.0):
+                    raise NotImplementedError("masked reset with a ray-caster drift range")
+                add_rows(sensor.drift)
+            else:
+                raise NotImplementedError(f"masked reset of sensor {type(sensor).__name__}")
+        # managers (manager_based_rl_env.py:365-391)
+        om, am, rm, tm, cm = (self.observation_manager, self.action_manager, self.reward_manager,
+                              self.termination_manager, self.command_manager)
+        if getattr(om, "_group_obs_class_term_cfgs", None) and any(om._group_obs_class_term_cfgs.values()):
+            raise NotImplementedError("masked reset of class-based observation terms")
+        if any(getattr(c, "history_length", 0) for cfgs in om._group_obs_term_cfgs.values() for c in cfgs):
+            raise NotImplementedError("masked reset of observation histories")
+        if rm._class_term_cfgs or tm._class_term_cfgs:
+            raise NotImplementedError("masked reset of class-based reward / termination terms")
+        add_rows(am._action)
+        add_rows(am._prev_action)
+        for term in am._terms.values():
+            if term.raw_actions.data_ptr() not in (am._action.data_ptr(),):
+                add_rows(term.raw_actions)
+        add(rm._episode_sums_block, len(rm.active_terms), 1, n)
+        self._reset_cmd_terms = []
+        for term in cm._terms.values():
+            if not isinstance(term, UniformVelocityCommand):
+                raise NotImplementedError(f"masked reset of command term {type(term).__name__}")
+            for v in term.metrics.values():
+                add_rows(v)
+            add_rows(term.command_counter)
+            self._reset_cmd_terms.append(term)
+        add_rows(self.episode_length_buf)
+        if len(fills) > 48:
+            raise NotImplementedError("masked reset: more than MDP_MAX_FILLS buffers")
+        arr = (L.MdpFill * len(fills))(*fills)
+        return arr, len(fills), keep
+
+    def _reset_masked(self, mask: torch.Tensor):
+        """``_reset_idx`` for the envs flagged in ``mask`` (``reset_buf``) with no host synchronisation: statistics as
+        device tensors, every zeroed buffer in ONE launch (``mdp_masked_fill``), commands resampled by their masked
+        kernel.  Events / curriculum stay out of scope like in ``_reset_idx``.  With an empty mask it is a no-op on the
+        state; the logged means are then 0 (the reference does not log at all in such a step)."""
+        from .. import _lib as L
+
+        if getattr(self, "_reset_plan", None) is None:
+            self._reset_plan = self._masked_reset_plan()
+        arr, count, _ = self._reset_plan
+        rm, tm, cm = self.reward_manager, self.termination_manager, self.command_manager
+        # statistics before anything is zeroed (reward_manager.py:115-121, command_manager.py:131-136,
+        # termination_manager.py:149-150)
+        m = mask.to(torch.float32)
+        cnt = m.sum().clamp_(min=1.0)
+        log = {}
+        sums = (rm._episode_sums_block[: len(rm.active_terms)] * m).sum(dim=1) / cnt / self.max_episode_length_s
+        for i, name in enumerate(rm.active_terms):
+            log["Episode_Reward/" + name] = sums[i]
+        for term_name, term in cm._terms.items():
+            for k, v in term.metrics.items():
+                log[f"Metrics/{term_name}/{k}"] = (v * m).sum() / cnt
+        done_counts = (tm._term_dones_block[: len(tm.active_terms)] & mask).sum(dim=1)
+        for i, name in enumerate(tm.active_terms):
+            log["Episode_Termination/" + name] = done_counts[i]
+        self.extras["log"] = log
+        L.check(L.lib.mdp_masked_fill(arr, count, mask.data_ptr(), self.num_envs, L.stream(self.device)))
+        for term in self._reset_cmd_terms:
+            term._launch(0.0, mask)           # CommandTerm.reset: resample (+ counter) for the flagged envs
 
     def _reset_idx(self, env_ids):
         """manager_based_rl_env.py:346-391 without events / curriculum (out of scope)."""

@@ -57,15 +57,24 @@ def frame_dict(rec, t: int) -> dict:
     return d
 
 
-def oracle_step(orc: VelocityStepOracle, rec, k: int):
+def oracle_step(orc: VelocityStepOracle, rec, k: int, auto_reset: bool = False):
     d = rec.decimation
     frames = [frame_dict(rec, 1 + k * d + i) for i in range(d)]
     cmd_u = rec.cmd_uniforms[k].numpy() if rec.cmd_uniforms is not None else None
     noise = {name: u[k].numpy() for name, u in rec.obs_noise.items()} if rec.obs_noise else None
-    return orc.step(rec.actions[k].numpy(), frames, cmd_u, noise)
+    return orc.step(rec.actions[k].numpy(), frames, cmd_u, noise, auto_reset=auto_reset)
 
 
-def replay_oracle(rec, steps: int, threads: int = 0):
-    """-> list of (obs, reward, terminated, time_outs) per env step."""
+def replay_oracle(rec, steps: int, threads: int = 0, auto_reset: bool = False, logs: list | None = None,
+                  episode_length0=None):
+    """-> list of (obs, reward, terminated, time_outs) per env step.  ``auto_reset``: done envs are reset inside the step
+    like ManagerBasedRLEnv.step does; ``logs`` (a list) then receives the step's ``extras["log"]`` dict or None."""
     orc = build_oracle(rec, threads)
-    return [oracle_step(orc, rec, k) for k in range(steps)]
+    if episode_length0 is not None:
+        orc.episode_length[:] = np.asarray(episode_length0, np.int64)
+    out = []
+    for k in range(steps):
+        out.append(oracle_step(orc, rec, k, auto_reset))
+        if logs is not None:
+            logs.append(orc.log)
+    return out

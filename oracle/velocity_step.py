@@ -117,7 +117,42 @@ class VelocityStepOracle:
         self.rc_last[ids] = self.rc_ts[ids]
         self.rc_outdated[ids] = False
 
-    def step(self, action, substep_frames, cmd_uniforms=None, obs_noise=None):
+    def reset_idx(self, ids, cmd_uniforms):
+        """ManagerBasedRLEnv._reset_idx (manager_based_rl_env.py:346-391) without curriculum / events (physics side):
+        scene.reset -> manager resets in the reference order -> episode counter.  Returns the ``extras["log"]`` dict."""
+        s, log = self.s, {}
+        # scene.reset: actuators (actuator_net.py:61-64), sensors (sensor_base.py:182-195, contact_sensor.py:136-155,
+        # ray_caster.py:106-113 with drift_range (0, 0))
+        if s["actuator"]["kind"] == "lstm":
+            L, H = self.h.shape[0], self.h.shape[2]
+            self.h.reshape(L, self.n, self.j, H)[:, ids] = 0.0
+            self.c.reshape(L, self.n, self.j, H)[:, ids] = 0.0
+        ct = self.contact
+        ct.ts[ids] = 0.0; ct.ts_last[ids] = 0.0; ct.outdated[ids] = True
+        ct.net[ids] = 0.0; ct.hist[ids] = 0.0
+        for buf in (ct.cur_air, ct.last_air, ct.cur_con, ct.last_con):
+            buf[ids] = 0.0
+        if s.get("height_scan") is not None:
+            self.rc_ts[ids] = 0.0; self.rc_last[ids] = 0.0; self.rc_outdated[ids] = True
+        # action manager (action_manager.py reset): prev_action, action, raw actions
+        self.prev_action[ids] = 0.0
+        self.action[ids] = 0.0
+        # reward manager (reward_manager.py:100-126)
+        max_len_s = F(s["episode_length_s"])
+        for i, (name, _, _) in enumerate(s["rewards"]):
+            log["Episode_Reward/" + name] = np.float32(np.mean(self.episode_sums[i, ids], dtype=np.float32) / max_len_s)
+            self.episode_sums[i, ids] = 0.0
+        # command manager (command_manager.py:120-149)
+        log["Metrics/base_velocity/error_vel_xy"] = np.float32(np.mean(self.command.m_xy[ids], dtype=np.float32))
+        log["Metrics/base_velocity/error_vel_yaw"] = np.float32(np.mean(self.command.m_yaw[ids], dtype=np.float32))
+        self.command.reset(ids, cmd_uniforms)
+        # termination manager (termination_manager.py:127-150)
+        for i, (name, _, _) in enumerate(s["terminations"]):
+            log["Episode_Termination/" + name] = int(np.count_nonzero(self.term_dones[i, ids]))
+        self.episode_length[ids] = 0
+        return log
+
+    def step(self, action, substep_frames, cmd_uniforms=None, obs_noise=None, auto_reset=False):
         """substep_frames: list of `decimation` dicts {root_state (N,13 wxyz), joint_pos, joint_vel, forces (N,B,3)}."""
         s = self.s
         self.prev_action = self.action.copy()
@@ -154,6 +189,12 @@ class VelocityStepOracle:
         # commands
         if cmd_uniforms is None:
             cmd_uniforms = np.zeros((self.n, 7), np.float32)
+        # reset of the envs that are done (manager_based_rl_env.py:214-229), between the rewards and the commands
+        self.log = None
+        if auto_reset:
+            ids = np.nonzero(self.terminated | self.time_outs)[0]
+            if ids.size:
+                self.log = self.reset_idx(ids, cmd_uniforms)
         self.command.compute(root, self.step_dt, cmd_uniforms)
         E["command"] = self.command.cmd
         # observations

@@ -153,3 +153,46 @@ def test_post_physics_step_rejects_what_it_does_not_cover(device):
     tr = L.MdpTerminationRewardArgs()
     with pytest.raises(ValueError, match="programs required"):
         L.check(L.lib.mdp_post_physics_step(16, None, 0.0, C.byref(tr), None, None, None, L.stream(device)))
+
+
+@pytest.mark.parametrize("name,mode", (("anymal_d_flat", True), ("anymal_d_flat", "masked"),
+                                       ("anymal_c_rough", True), ("anymal_c_rough", "masked")))
+def test_auto_reset_inside_the_step(device, name, mode):
+    """ManagerBasedRLEnv.step with its reset branch (manager_based_rl_env.py:214-229, 346-391; events and curriculum
+    are physics-side and out of scope): envs start close to their time limit, so every step resets some of them --
+    LSTM states, contact-sensor and ray-caster bookkeeping, action buffers, episode sums, command metrics / counter /
+    resampling, episode counter.  ``True`` is the reference's id-list path (nonzero() on the host), ``"masked"`` the
+    sync-free one (mdp_masked_fill + masked command kernel); both must reproduce the oracle, statistics included."""
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+    from oracle.harness import replay_oracle
+
+    n, steps = 96, 8
+    kw = dict(small_terrain=True) if "rough" in name else {}
+    env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=31, **kw)
+    env.auto_reset = mode
+    g = torch.Generator().manual_seed(5)
+    start = env.max_episode_length - torch.randint(1, steps + 3, (n,), generator=g)
+    env.episode_length_buf.copy_(start)
+    outs, logs = [], []
+    for t in range(steps):
+        rec.feed(t)
+        env.extras.pop("log", None)
+        obs, rew, term, trunc, extras = env.step(rec.actions[t].to(device))
+        outs.append((to_np(obs["policy"]), to_np(rew), to_np(term), to_np(trunc)))
+        logs.append({k: float(v) for k, v in extras["log"].items()} if "log" in extras else None)
+    ref_logs = []
+    ref = replay_oracle(rec, steps, auto_reset=True, logs=ref_logs, episode_length0=start.numpy())
+    compare(outs, ref)
+    assert sum(o[3].sum() for o in outs) >= n // 2          # the time limit did fire
+    checked = 0
+    for t in range(steps):
+        if ref_logs[t] is None:
+            continue                                        # no env done: the reference does not log
+        assert logs[t] is not None
+        for key, exp in ref_logs[t].items():
+            assert key in logs[t], key
+            np.testing.assert_allclose(logs[t][key], exp, rtol=1e-4, atol=1e-6, err_msg=f"{key} step {t}")
+            checked += 1
+    assert checked > 0
