@@ -257,3 +257,46 @@ def test_stats_kernels(device):
     o = to_np(out).reshape(5, 2)
     np.testing.assert_allclose(o[:, 0], vals.astype(np.float64)[:, mask].sum(1), rtol=1e-12, atol=1e-9)
     assert np.all(o[:, 1] == mask.sum())
+
+
+def test_masked_fill(device):
+    """mdp_masked_fill == ``buf[env_ids] = value`` for every buffer of the call: env-major (N, k) float / int64 / bool
+    buffers, a term-major (k, N) block, untouched rows bit-identical; empty mask = no-op; too many buffers = ValueError."""
+    import ctypes as C
+    import struct
+
+    import torch
+
+    from isaaclab_amd import _lib as L
+
+    n = 333
+    g = torch.Generator().manual_seed(3)
+    mask = (torch.rand(n, generator=g) < 0.3).to(device)
+    a = torch.randn(n, 7, generator=g).to(device)
+    b = torch.randint(-5, 5, (n,), generator=g).to(device)                      # int64
+    c = torch.zeros(n, dtype=torch.bool, device=device)
+    d = torch.randn(5, n, generator=g).to(device)                               # term-major
+    ref = [t.clone() for t in (a, b, c, d)]
+    ref[0][mask] = 0.5
+    ref[1][mask] = 0
+    ref[2][mask] = True
+    ref[3][:, mask] = 0.0
+
+    def rec(t, count, env_stride, elem_stride, value):
+        f = L.MdpFill()
+        f.ptr, f.elem_bytes, f.count, f.env_stride, f.elem_stride = t.data_ptr(), t.element_size(), count, env_stride, elem_stride
+        f.value_bits = struct.unpack("<I", struct.pack("<f", value))[0] if t.dtype == torch.float32 else int(value)
+        return f
+
+    fills = [rec(a, 7, 7, 1, 0.5), rec(b, 1, 1, 1, 0), rec(c, 1, 1, 1, 1), rec(d, 5, 1, n, 0.0)]
+    arr = (L.MdpFill * len(fills))(*fills)
+    L.check(L.lib.mdp_masked_fill(arr, len(fills), mask.data_ptr(), n, L.stream(device)))
+    for got, exp in zip((a, b, c, d), ref):
+        assert torch.equal(got, exp)
+    none = torch.zeros(n, dtype=torch.bool, device=device)
+    L.check(L.lib.mdp_masked_fill(arr, len(fills), none.data_ptr(), n, L.stream(device)))
+    for got, exp in zip((a, b, c, d), ref):
+        assert torch.equal(got, exp)
+    many = (L.MdpFill * 49)(*([fills[0]] * 49))
+    with pytest.raises(ValueError, match="at most"):
+        L.check(L.lib.mdp_masked_fill(many, 49, mask.data_ptr(), n, L.stream(device)))
