@@ -231,6 +231,9 @@ def main():
     value = world * args.envs * K / elapsed
 
     out = None
+    resets = None
+    if getattr(env, "_post_reset_log", None) is not None:
+        resets = float(env._post_reset_log[0].item())      # envs the last timed step reset (its own log count)
     if rank == 0:
         roof = measure_roofline(env, args)
         cpu = None
@@ -245,7 +248,8 @@ def main():
                                    f" 187-ray height scan on a {env.mesh.num_tris if hasattr(env, 'mesh') else 0}-triangle terrain,"
                                    f" ring of {ring * env.cfg.decimation} synthetic state frames",
                        "envs_per_gpu": args.envs, "hip_graph": graph is not None,
-                       "stats_allreduce_every": args.stats_every},
+                       "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset,
+                       "reset_envs_last_step": resets},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

@@ -681,6 +681,42 @@ int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float 
                           const mdp_velocity_command_args_t* command, const mdp_obs_args_t* observation,
                           const mdp_raycaster_update_args_t* cast, void* stream);
 
+/* The same launch with the reset branch of the step in it (manager_based_rl_env.py:214-229, 346-391 without events and
+ * curriculum): between its rewards and its command update a manager block resets the envs whose `dones` flag the
+ * launch has just written -- the buffers of `fills` (DEVICE array of mdp_fill_t records, as for mdp_masked_fill) and
+ * the command term (CommandTerm.reset: metrics, counter, resample) -- and adds the episode statistics of those envs to
+ * `log_sums`; the last manager block to finish turns the sums into the values the managers' reset() log
+ * (reward_manager.py:115-121, command_manager.py:131-136, termination_manager.py:149-150) in `log`: log[0] = number of
+ * reset envs, then per reward term mean(episode sum) / max_episode_length_s, the means of the two command metrics, and
+ * one count per termination term (all 0 when no env was done).  Blocks keep their partial sums in slots of their own
+ * and the last one adds them in a fixed order (no floating-point atomics: the log is reproducible); word 0 of
+ * `log_sums` is the block ticket, which the caller zeroes once, when it allocates the workspace.  The ray caster's own
+ * reset (timestamps zeroed, flagged outdated, cast again by the observation) cannot ride in this launch -- its cast
+ * blocks run concurrently with the blocks that find out which envs are done -- so the caller follows it with
+ * mdp_raycaster_update_flagged(dones). */
+typedef struct {
+    const mdp_fill_t* fills;   /* device pointer */
+    int32_t num_fills;
+    float max_episode_length_s;
+    double* log_sums;          /* device workspace, 1 + (1 + Tr + 2 + Tt) * ceil(num_envs / 8) doubles */
+    float* log;                /* device, 1 + Tr + 2 + Tt floats (out) */
+} mdp_post_reset_args_t;
+
+int mdp_post_physics_step_with_reset(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                     const mdp_termination_reward_args_t* termination_reward,
+                                     const mdp_velocity_command_args_t* command, const mdp_obs_args_t* observation,
+                                     const mdp_raycaster_update_args_t* cast, const mdp_post_reset_args_t* reset,
+                                     void* stream);
+
+/* RayCaster.reset(env_ids) + the lazy re-evaluation the next data access triggers (sensor_base.py:182-195, 284-293;
+ * ray_caster.py:106-113, 220-260), for the envs flagged in `reset_mask` (device, num_envs bytes, may be null): their
+ * timestamps go to 0 and they count as outdated; then every outdated env -- and only those -- is cast again and, with
+ * cast->scan, gets its height_scan observation columns rewritten.  No update(dt) bookkeeping (cast->tick_dt is
+ * ignored).  Same coverage as the cast member of mdp_post_physics_step (vertical rays, yaw-only, grid mesh), else
+ * MDP_ERR_UNSUPPORTED. */
+int mdp_raycaster_update_flagged(int num_envs, const mdp_raycaster_update_args_t* cast, const uint8_t* reset_mask,
+                                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,13 @@ class MdpFill(C.Structure):
     ]
 
 
+class MdpPostResetArgs(C.Structure):
+    """Mirror of ``mdp_post_reset_args_t``."""
+
+    _fields_ = [("fills", C.c_void_p), ("num_fills", C.c_int32), ("max_episode_length_s", C.c_float),
+                ("log_sums", C.c_void_p), ("log", C.c_void_p)]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -681,9 +681,11 @@ struct PostArgs {
     mdp_velocity_command_args_t cmd;
     const mdp_term_t* oterms; int To; const int32_t* opool; const int16_t* col2term; int O;
     float* obs; int ld_obs; uint64_t* orng; unsigned orng_base; int ouses_rng;
+    // ---- reset branch (k_post_physics<.., true> only)
+    const mdp_fill_t* fills; int num_fills; float max_episode_length_s; double* log_sums; float* log;
 };
 
-template <int BATCH>
+template <int BATCH, bool RESET>
 __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
@@ -718,6 +720,17 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
             dst[i] = i < wo ? so[i] : (i < wo + wt ? st[i - wo] : sr[i - wo - wt]);
         for (int i = threadIdx.x; i < a.O; i += blockDim.x) col2term[i] = a.col2term[i];
     }
+    // reset variant: the fill records behind the column map (8-byte aligned), the block's done flags in s_done
+    mdp_fill_t* fills = reinterpret_cast<mdp_fill_t*>(
+        s_dyn + (((size_t)(reinterpret_cast<unsigned char*>(col2term + a.O) - s_dyn) + 7) & ~(size_t)7));
+    __shared__ uint8_t s_done[64];
+    __shared__ int s_last;
+    if (RESET) {
+        constexpr int FW = (int)(sizeof(mdp_fill_t) / 4);
+        const uint32_t* sf = reinterpret_cast<const uint32_t*>(a.fills);
+        uint32_t* df = reinterpret_cast<uint32_t*>(fills);
+        for (int i = threadIdx.x; i < a.num_fills * FW; i += blockDim.x) df[i] = sf[i];
+    }
     // ---- scene.update(physics_dt) for this block's envs (interactive_scene.py:496-513)
     if (a.has_upd) scene_update_envs(a.upd, a.physics_dt, e0, e1);
     MDP_STAMP(1);
@@ -743,6 +756,7 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
         if (a.truncated) a.truncated[e] = trunc ? 1 : 0;
         if (a.terminated) a.terminated[e] = term ? 1 : 0;
         if (a.dones) a.dones[e] = (trunc || term) ? 1 : 0;
+        if (RESET) s_done[lane] = (trunc || term) ? 1 : 0;
     }
     __threadfence_block();
     __syncthreads();
@@ -764,6 +778,85 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
         for (int ti = 0; ti < a.Tr; ++ti)
             if (rterms[ti].weight != 0.0f) total += s_val[ti * 64 + lane];
         a.reward[e] = total;
+    }
+    // ---- reset of the envs that are done (manager_based_rl_env.py:214-229, 346-391): between rewards and commands
+    if (RESET) {
+        __threadfence_block();
+        __syncthreads();                                  // episode sums and reward of every env of the block are written
+        // statistics of the reset envs: row r of {count, Tr episode sums, 2 command metrics, Tt termination counts},
+        // rows over the waves, envs over the lanes (one load per lane, no chain), wave sum
+        const int rows = 1 + a.Tr + 2 + a.Tt;
+        const bool mine = e < N && s_done[lane] != 0;
+        __shared__ uint8_t s_list[64];                    // local ids of the block's done envs, s_nd of them
+        __shared__ int s_nd;
+        if (wave == 0) {
+            const unsigned long long m = __ballot(mine);
+            if (mine) s_list[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
+            if (lane == 0) s_nd = __popcll(m);
+        }
+        // every block stores its row sums in a slot of its own (no atomics: the sums do not depend on block timing)
+        double* part = a.log_sums + 1 + (size_t)b * rows;
+        for (int r0 = wave; r0 < rows; r0 += 8 * nwaves) {
+            // eight rows at a time: their loads are issued back to back, then the eight wave sums are taken
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + j * nwaves;
+                v[j] = 0.0f;
+                if (mine && r < rows) {
+                    if (r == 0) v[j] = 1.0f;
+                    else if (r <= a.Tr) v[j] = a.sums[(int64_t)rterms[r - 1].out_offset * N + e];
+                    else if (r == a.Tr + 1) v[j] = a.has_cmd ? a.cmd.metric_error_vel_xy[e] : 0.0f;
+                    else if (r == a.Tr + 2) v[j] = a.has_cmd ? a.cmd.metric_error_vel_yaw[e] : 0.0f;
+                    else v[j] = a.term_dones[(int64_t)tterms[r - a.Tr - 3].out_offset * N + e] ? 1.0f : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = r0 + j * nwaves;
+                double d = (double)v[j];
+                for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+                // device-scope store: written through to where the last block reads it.  (A __threadfence() here would
+                // write back the whole XCD's L2 -- everything the cast blocks have produced so far -- once per block.)
+                if (lane == 0 && r < rows)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + r),
+                                       (unsigned long long)__double_as_longlong(d), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0);                    // those stores are acknowledged before the block takes its ticket
+        __syncthreads();                                  // statistics read before anything is zeroed
+        // the last manager block to get here will add the slots up and publish the log values -- at the very end of its
+        // own work: the sums sit in memory, several round trips away, and nothing in this launch waits for the log
+        unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.log_sums);
+        if (threadIdx.x == 0)
+            s_last = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull ==
+                     (unsigned long long)a.nb_post;
+        // the buffers _reset_idx zeroes, for the done envs of this block (mdp_fill_t records, see mdp_masked_fill)
+        // a wave per done env, lanes over the elements of each buffer (nothing to do in a block without done envs)
+        const int nd = s_nd;
+        for (int j = wave; j < nd; j += nwaves) {
+            const int ee = e0 + s_list[j];
+            for (int fi = 0; fi < a.num_fills; ++fi) {
+                const mdp_fill_t& f = fills[fi];
+                const int64_t base = (int64_t)ee * f.env_stride;
+                for (int k = lane; k < f.count; k += 64) {
+                    const int64_t at = base + (int64_t)k * f.elem_stride;
+                    if (f.elem_bytes == 4) reinterpret_cast<uint32_t*>(f.ptr)[at] = (uint32_t)f.value_bits;
+                    else if (f.elem_bytes == 8) reinterpret_cast<uint64_t*>(f.ptr)[at] = f.value_bits;
+                    else reinterpret_cast<uint8_t*>(f.ptr)[at] = (uint8_t)f.value_bits;
+                }
+            }
+        }
+        // CommandTerm.reset (command_manager.py:120-149): metrics, counter, resample
+        if (a.has_cmd && wave == 0 && e < N && s_done[lane]) {
+            uint64_t seed = 0, epoch = 0;
+            if (a.cmd.rng_state) { seed = a.cmd.rng_state[0]; epoch = a.cmd.rng_state[4 + b]; }
+            velocity_command_env(a.cmd.cfg, e, a.cmd.root_state, a.cmd.ld_state, a.cmd.vel_command_b, a.cmd.heading_target,
+                                 a.cmd.is_heading_env, a.cmd.is_standing_env, a.cmd.time_left, a.cmd.command_counter,
+                                 a.cmd.metric_error_vel_xy, a.cmd.metric_error_vel_yaw, 0.0f, seed, epoch | (3ull << 61),
+                                 a.cmd.injected_u, a.dones);
+        }
+        __threadfence_block();
     }
     // ---- command_manager.compute(step_dt) (command_manager.py:151-187, velocity_command.py:111-160): after the
     // rewards, which read the previous command
@@ -803,6 +896,57 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
             a.obs[(int64_t)ee * a.ld_obs + c] = v;
         }
         if (a.ouses_rng && threadIdx.x == 0) a.orng[a.orng_base + b] = epoch + 1;
+    }
+    MDP_STAMP(6);
+    if (RESET) {
+        if (s_last) {                                     // block-uniform, written before the command phase's barriers
+            // thread (r, p) adds the slots of blocks p, p + P, ... for row r (independent, coalesced loads, 32 in flight),
+            // then the P partial sums of a row are added in order: the log does not depend on block timing
+            __shared__ double s_red[256];
+            const int rows = 1 + a.Tr + 2 + a.Tt;
+            double* s_sum = reinterpret_cast<double*>(s_val);
+            const unsigned long long* all = reinterpret_cast<const unsigned long long*>(a.log_sums + 1);
+            int P = (blockDim.x < 256 ? (int)blockDim.x : 256) / rows;
+            if (P < 1) P = 1;
+            __syncthreads();                              // s_val: the last reader was the reward total
+            if ((int)threadIdx.x < rows * P) {
+                const int p = threadIdx.x / rows, r = threadIdx.x - p * rows;
+                double v = 0.0;
+                for (unsigned b0 = p; b0 < a.nb_post; b0 += 32u * P) {
+                    unsigned long long w[32];
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) {
+                        const unsigned bb = b0 + (unsigned)j * P;
+                        w[j] = bb < a.nb_post ? __hip_atomic_load(all + (size_t)bb * rows + r, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 32; ++j) v += __longlong_as_double((long long)w[j]);
+                }
+                s_red[threadIdx.x] = v;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < rows) {
+                double v = 0.0;
+                for (int p = 0; p < P; ++p) v += s_red[p * rows + threadIdx.x];
+                s_sum[threadIdx.x] = v;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < rows) {
+                const int r = threadIdx.x;
+                const double cnt = s_sum[0], sum = s_sum[r];
+                float v;
+                if (r == 0 || r > a.Tr + 2) v = (float)sum;                 // counts
+                else {
+                    v = cnt > 0.0 ? (float)(sum / cnt) : 0.0f;              // torch.mean over the reset envs
+                    if (r <= a.Tr) v = v / a.max_episode_length_s;
+                }
+                a.log[r] = v;
+            }
+            if (threadIdx.x == 0)                                           // ready for the next launch
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.log_sums), 0ull, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     MDP_STAMP(5);
 }
@@ -1011,10 +1155,10 @@ extern "C" int mdp_termination_reward_compute(mdp_program_t* tp, mdp_program_t* 
 
 MDP_STAMP_SETTER(mdp_debug_stamps_programs)
 
-extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float physics_dt,
-                                     const mdp_termination_reward_args_t* tr, const mdp_velocity_command_args_t* command,
-                                     const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
-                                     void* stream) {
+static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                               const mdp_termination_reward_args_t* tr, const mdp_velocity_command_args_t* command,
+                               const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
+                               const mdp_post_reset_args_t* reset, void* stream) {
     MDP_REQUIRE(num_envs >= 0, "negative num_envs");
     MDP_REQUIRE(tr && tr->termination && tr->reward, "termination / reward programs required");
     mdp_program_t* tp = tr->termination;
@@ -1107,12 +1251,43 @@ extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* upd
             lds += (size_t)op->num_terms * sizeof(mdp_term_t) + (size_t)a.O * sizeof(int16_t) + 16;
         }
     }
+    if (reset && reset->num_fills > 0) lds += (size_t)reset->num_fills * sizeof(mdp_fill_t) + 8;
     if (lds > 60 * 1024) return fail(MDP_ERR_UNSUPPORTED, "programs too large for the LDS staging area (%zu B)", lds);
     a.post_envs = post_envs;
     a.nb_post = (unsigned)(((int64_t)num_envs + post_envs - 1) / post_envs);
-    hipLaunchKernelGGL(k_post_physics<2>, dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
+    if (reset) {
+        MDP_REQUIRE(reset->log && reset->log_sums && (reset->fills || reset->num_fills == 0) && reset->num_fills >= 0,
+                    "reset: null pointer");
+        MDP_REQUIRE(reset->max_episode_length_s > 0.0f, "reset: max_episode_length_s must be positive");
+        MDP_REQUIRE(tr->dones && tr->term_dones && tr->episode_sums, "reset needs dones, term_dones and episode_sums");
+        MDP_REQUIRE(1 + a.Tr + 2 + a.Tt <= std::min(threads, 256), "reset: more statistics rows than a block reduces");
+        MDP_REQUIRE(reset->num_fills <= MDP_MAX_FILLS, "reset: more than MDP_MAX_FILLS buffers");
+        MDP_REQUIRE(post_envs >= 8, "reset: the log_sums workspace is sized for blocks of >= 8 envs (MDP_POST_ENVS=%d)", post_envs);
+        a.fills = reset->fills; a.num_fills = reset->num_fills; a.log = reset->log;
+        a.log_sums = reset->log_sums; a.max_episode_length_s = reset->max_episode_length_s;
+        hipLaunchKernelGGL((k_post_physics<2, true>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
+    } else {
+        hipLaunchKernelGGL((k_post_physics<2, false>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
+    }
     MDP_LAUNCH_CHECK();
     return MDP_OK;
+}
+
+extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                     const mdp_termination_reward_args_t* tr, const mdp_velocity_command_args_t* command,
+                                     const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
+                                     void* stream) {
+    return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, nullptr, stream);
+}
+
+extern "C" int mdp_post_physics_step_with_reset(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                                const mdp_termination_reward_args_t* tr,
+                                                const mdp_velocity_command_args_t* command,
+                                                const mdp_obs_args_t* observation,
+                                                const mdp_raycaster_update_args_t* cast,
+                                                const mdp_post_reset_args_t* reset, void* stream) {
+    MDP_REQUIRE(reset, "null reset arguments");
+    return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, reset, stream);
 }
 
 extern "C" int mdp_obs_postprocess(const mdp_term_t* term, int num_envs, float* data, int ld, uint64_t seed,

@@ -26,6 +26,7 @@ struct RaycasterUpdateArgs {
     uint8_t* outdated;
     mdp_height_scan_obs_t scan;
     float tick_dt, period;
+    const uint8_t* reset_mask;   // FLAGGED instantiation only (mdp_raycaster_update_flagged)
 };
 
 // height_scan observation column of ray r of env e, written by the cast kernels (mdp_height_scan_obs_t)
@@ -45,17 +46,48 @@ __device__ __forceinline__ void scan_store(const mdp_height_scan_obs_t& sc, int 
 // post-process their height.
 constexpr int RCU_MAX_EPB = 256;   // blockDim.x <= 1024 and num_rays >= 1; callers keep epb <= this
 
+// ray r of env e: start rotated by the yaw quaternion, one grid-cell walk, hit point and height_scan column stored
+template <int BATCH>
+__device__ __forceinline__ void raycaster_down_ray(const RaycasterUpdateArgs& a, int e, int r, V3 pos, Q4 qr, uint64_t seed,
+                                                   uint64_t epoch) {
+    const mdp_mesh_view_t& mesh = a.mesh;
+    const int R = a.R;
+    const float inf = __builtin_inff();
+    V3 s = quat_apply(qr, ld3(a.starts_l + 3 * r));
+    s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
+    V3 d = ld3(a.dirs_l + 3 * r);
+    mdp_hit_t h;
+    if (mesh.finite) {
+#ifdef MDP_STAMPS
+        int walk = 0;   // diagnostic: records in the cell / batches read by this ray (tools/kernel_stamps.py)
+        h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &walk);
+        if (g_stamps) g_stamps[8192 * 8 + (size_t)e * R + r] = (unsigned long long)walk;
+#else
+        h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist);
+#endif
+    } else {
+        mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
+        h = mdp_rc_grid_down<BATCH>(&mesh, &ray, a.max_dist);
+    }
+    MDP_STAMP(4);
+    float* o = a.hits + ((int64_t)e * R + r) * 3;
+    float hz = inf;
+    if (h.face >= 0) {
+        hz = s.z + h.t * d.z;
+        o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = hz;
+    } else {
+        o[0] = inf; o[1] = inf; o[2] = inf;
+    }
+    if (a.scan.obs) scan_store(a.scan, e, r, R, pos.z, hz, seed, epoch);
+}
+
 template <int BATCH>
 __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpdateArgs& a, int epb, int slot_w,
                                                              unsigned block, unsigned nblocks) {
     __shared__ float s_env[RCU_MAX_EPB][6];   // pos.xyz, yaw quaternion (w, z), cast flag
-    const mdp_mesh_view_t& mesh = a.mesh;
     const int N = a.N, R = a.R;
-    const float* __restrict__ starts_l = a.starts_l;
-    const float* __restrict__ dirs_l = a.dirs_l;
     float* __restrict__ hits = a.hits;
     const mdp_height_scan_obs_t& scan = a.scan;
-    const float inf = __builtin_inff();
     const int le = threadIdx.x / slot_w;
     const int lr = threadIdx.x - le * slot_w;
     uint64_t seed = 0, epoch = 0;
@@ -100,38 +132,66 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
             const V3 pos = V3{se[0], se[1], se[2]};
             const Q4 qr = Q4{se[3], 0.0f, 0.0f, se[4]};
             MDP_STAMP(3);
-            for (int r = lr; r < R; r += slot_w) {
-                V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
-                s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
-                V3 d = ld3(dirs_l + 3 * r);
-                mdp_hit_t h;
-                if (mesh.finite) {
-#ifdef MDP_STAMPS
-                    int walk = 0;   // diagnostic: records in the cell / batches read by this ray (tools/kernel_stamps.py)
-                    h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &walk);
-                    if (g_stamps) g_stamps[8192 * 8 + (size_t)e * R + r] = (unsigned long long)walk;
-#else
-                    h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist);
-#endif
-                } else {
-                    mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);
-                    h = mdp_rc_grid_down<BATCH>(&mesh, &ray, a.max_dist);
-                }
-                MDP_STAMP(4);
-                float* o = hits + ((int64_t)e * R + r) * 3;
-                float hz = inf;
-                if (h.face >= 0) {
-                    hz = s.z + h.t * d.z;
-                    o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = hz;
-                } else {
-                    o[0] = inf; o[1] = inf; o[2] = inf;
-                }
-                if (scan.obs) scan_store(scan, e, r, R, pos.z, hz, seed, epoch);
-            }
+            for (int r = lr; r < R; r += slot_w) raycaster_down_ray<BATCH>(a, e, r, pos, qr, seed, epoch);
         }
         __syncthreads();   // s_env is rewritten by the next env group
     }
     if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
+}
+
+// The reset + lazy re-evaluation form (mdp_raycaster_update_flagged): envs of reset_mask get their timestamps zeroed and
+// count as outdated, there is no tick, and only outdated envs are cast (the others keep their observation columns).
+// Few envs are flagged in a step, so a block looks at RCF_ENVS envs with one lane each -- bookkeeping, pose, yaw
+// quaternion -- and then casts the flagged ones one after the other with all its threads: a launch with nothing to do
+// is N / RCF_ENVS blocks that read three flags per env and leave.
+constexpr int RCF_ENVS = 16;
+
+template <int BATCH>
+__device__ __forceinline__ void raycaster_update_flagged_blocks(const RaycasterUpdateArgs& a, unsigned block) {
+    __shared__ float s_fenv[RCF_ENVS][6];
+    const int N = a.N, R = a.R;
+    const mdp_height_scan_obs_t& scan = a.scan;
+    uint64_t seed = 0, epoch = 0;
+    const int base = (int)block * RCF_ENVS;
+    if ((int)threadIdx.x < RCF_ENVS) {
+        const int le = threadIdx.x, e = base + le;
+        bool od = false;
+        if (e < N) {
+            od = a.outdated[e] != 0;
+            float t_now = a.ts[e];
+            if (a.reset_mask && a.reset_mask[e]) {       // sensor_base.py:182-195
+                t_now = 0.0f;
+                a.ts[e] = 0.0f;
+                od = true;
+            }
+            if (od) {
+                const float* p = a.pose + (int64_t)e * a.ld_pose;
+                V3 pos = ld3(p);
+                if (a.drift) { pos.x += a.drift[3 * e]; pos.y += a.drift[3 * e + 1]; pos.z += a.drift[3 * e + 2]; }
+                Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+                Q4 qr = yaw_quat(q);
+                float* se = s_fenv[le];
+                se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
+                st3(a.pos_w + 3 * (int64_t)e, pos);
+                st4(a.quat_w + 4 * (int64_t)e, q);
+                a.ts_last[e] = t_now;
+                a.outdated[e] = 0;
+            }
+        }
+        s_fenv[le][5] = od ? 1.0f : 0.0f;
+    }
+    __syncthreads();
+    bool any = false;
+    for (int le = 0; le < RCF_ENVS; ++le) {
+        const float* se = s_fenv[le];
+        if (se[5] == 0.0f) continue;                     // block-uniform
+        if (!any && scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + block]; }
+        any = true;
+        const V3 pos = V3{se[0], se[1], se[2]};
+        const Q4 qr = Q4{se[3], 0.0f, 0.0f, se[4]};
+        for (int r = threadIdx.x; r < R; r += blockDim.x) raycaster_down_ray<BATCH>(a, base + le, r, pos, qr, seed, epoch);
+    }
+    if (any && scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
 }
 
 }  // namespace mdp

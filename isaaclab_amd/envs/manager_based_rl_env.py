@@ -104,12 +104,15 @@ class ManagerBasedRLEnv:
         if deferred is None:
             self.action_manager.process_action(action.to(self.device))
         decimation = self.cfg.decimation
-        concurrent = (self.concurrent_post_physics and not self.auto_reset and self._can_fuse_post_physics()
+        masked = self.auto_reset == "masked"
+        concurrent = (self.concurrent_post_physics and (not self.auto_reset or masked) and self._can_fuse_post_physics()
                       and not self._post_physics_reads_lazy_sensor())
         om = self.observation_manager
         # sensor-owned observation columns (height scan) come from the cast kernel, on its own stream
         split = concurrent and om.can_split_sensor_terms()
         early_cast = split and self.scene.fused_update and len(om.scan_sensors()) > 0
+        if masked and not (early_cast and self.single_launch_post_physics):
+            split = early_cast = concurrent = False   # resets sit between rewards and commands: serial launches below
         self.action_manager.apply_action()
         self.scene.write_data_to_sim(joint_action=deferred)
         for k in range(decimation):
@@ -127,9 +130,9 @@ class ManagerBasedRLEnv:
                 self.scene.update(dt=self.physics_dt)
             # (with early_cast the last scene.update runs after the loop, next to or inside the post-physics launches)
         self.common_step_counter += 1
-        if early_cast and self.single_launch_post_physics and self._post_physics_single_launch():
+        if early_cast and self.single_launch_post_physics and self._post_physics_single_launch(reset=masked):
             pass
-        elif concurrent:
+        elif concurrent and not masked:
             # Without the reset path between them (manager_based_rl_env.py:214-229) the chain terminations -> rewards ->
             # command update -> observations and the height-scan cast do not depend on each other: they go to two
             # streams (two branches of a captured hipGraph) and join at the end of the step.  The cast reads the sensor
@@ -159,6 +162,8 @@ class ManagerBasedRLEnv:
             if not split:
                 self.obs_buf = om.compute()
         else:
+            if early_cast:                              # masked resets and the single launch declined the task
+                self.scene.update(dt=self.physics_dt)
             if self.fuse_post_physics and self._can_fuse_post_physics():
                 self._termination_reward_fused()
             else:
@@ -192,7 +197,7 @@ class ManagerBasedRLEnv:
                 return True
         return False
 
-    def _post_physics_single_launch(self) -> bool:
+    def _post_physics_single_launch(self, reset: bool = False) -> bool:
         """manager_based_rl_env.py:195-238 (last ``scene.update``, episode counter, terminations, rewards, command,
         observations incl. the height-scan cast) as ONE launch, ``mdp_post_physics_step``.  False when the task does not
         have the shape that entry point covers; the caller then uses the separate launches."""
@@ -227,14 +232,51 @@ class ManagerBasedRLEnv:
         ca = terms[0].fill_post_physics(self.step_dt)
         cast = sensor.fill_post_physics(scan, self.physics_dt)
         oprog.run_before()
-        L.check(L.lib.mdp_post_physics_step(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
-                                            C.byref(obs_args), C.byref(cast), L.stream(self.device)))
+        if reset:
+            # reset branch inside the launch; the ray caster's own reset follows it (see mdp_post_physics_step_with_reset)
+            if getattr(self, "_post_reset_plan", None) is None:
+                self._post_reset_plan = self._masked_reset_plan(separate_sensor=sensor)
+                rows = 1 + len(rm.active_terms) + 2 + len(tm.active_terms)
+                # block ticket (zeroed once) + one slot of row sums per manager block of the launch
+                self._post_reset_sums = torch.zeros(1 + rows * ((self.num_envs + 7) // 8), dtype=torch.float64,
+                                                    device=self.device)
+                self._post_reset_log = torch.zeros(rows, dtype=torch.float32, device=self.device)
+            _, count, _, blob, sarr, scount = self._post_reset_plan
+            ra = L.MdpPostResetArgs()
+            ra.fills, ra.num_fills, ra.max_episode_length_s = blob.data_ptr(), count, float(self.max_episode_length_s)
+            ra.log_sums, ra.log = self._post_reset_sums.data_ptr(), self._post_reset_log.data_ptr()
+            L.check(L.lib.mdp_post_physics_step_with_reset(
+                self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca), C.byref(obs_args),
+                C.byref(cast), C.byref(ra), L.stream(self.device)))
+            # RayCaster.reset of the done envs + their recast (the observation's lazy evaluation in the reference)
+            L.check(L.lib.mdp_raycaster_update_flagged(self.num_envs, C.byref(cast), tm._dones_buf.data_ptr(),
+                                                       L.stream(self.device)))
+            self._publish_reset_log()
+        else:
+            L.check(L.lib.mdp_post_physics_step(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
+                                                C.byref(obs_args), C.byref(cast), L.stream(self.device)))
         self.reset_buf = tm._dones_buf
         self.reward_buf = rm._reward_buf
         om._obs_buffer = {group_name: out}
         self.obs_buf = om._obs_buffer
         self._single_launch_steps = getattr(self, "_single_launch_steps", 0) + 1
         return True
+
+    def _publish_reset_log(self):
+        """``extras["log"]`` of the step: views of a copy of the values the post-physics launch published (device
+        tensors; reward_manager.py:115-121, command_manager.py:131-136, termination_manager.py:149-150)."""
+        rm, tm, cm = self.reward_manager, self.termination_manager, self.command_manager
+        p = self._post_reset_log.clone()        # the launch overwrites its buffer next step; callers keep these
+        nr = len(rm.active_terms)
+        log = {}
+        for i, name in enumerate(rm.active_terms):
+            log["Episode_Reward/" + name] = p[1 + i]
+        term_name = next(iter(cm._terms))
+        log[f"Metrics/{term_name}/error_vel_xy"] = p[1 + nr]
+        log[f"Metrics/{term_name}/error_vel_yaw"] = p[2 + nr]
+        for i, name in enumerate(tm.active_terms):
+            log["Episode_Termination/" + name] = p[3 + nr + i]
+        self.extras["log"] = log
 
     def _mesh_has_grid(self, mesh) -> bool:
         cache = self.__dict__.setdefault("_mesh_grid_cache", {})
@@ -259,9 +301,10 @@ class ManagerBasedRLEnv:
         self.reward_buf = rm._reward_buf
 
     # -- reset by mask (the reset path without its host syncs) ------------------------------
-    def _masked_reset_plan(self):
+    def _masked_reset_plan(self, separate_sensor=None):
         """The per-env state ``_reset_idx`` zeroes, as ``mdp_fill_t`` records (built once).  Raises
-        ``NotImplementedError`` for state this path does not know how to reset."""
+        ``NotImplementedError`` for state this path does not know how to reset.  ``separate_sensor``: its three
+        bookkeeping arrays go to a second table (the post-physics launch resets them in a call of their own)."""
         import ctypes as C
         import struct
 
@@ -301,10 +344,15 @@ class ManagerBasedRLEnv:
                     pass                                      # stateless
                 else:
                     raise NotImplementedError(f"masked reset of actuator {type(act).__name__}")
+        sensor_fills = []
         for sensor in self.scene.sensors.values():
+            first = len(fills)
             add_rows(sensor._timestamp)
             add_rows(sensor._timestamp_last_update)
             add_rows(sensor._is_outdated, 1)
+            if sensor is separate_sensor:
+                sensor_fills = fills[first:]
+                del fills[first:]
             if isinstance(sensor, ContactSensor):
                 d = sensor.data
                 add_rows(d.net_forces_w)
@@ -346,7 +394,12 @@ class ManagerBasedRLEnv:
         if len(fills) > 48:
             raise NotImplementedError("masked reset: more than MDP_MAX_FILLS buffers")
         arr = (L.MdpFill * len(fills))(*fills)
-        return arr, len(fills), keep
+        if separate_sensor is None:
+            return arr, len(fills), keep
+        # device copy of the table for the post-physics launch + the sensor's own table
+        blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+        sarr = (L.MdpFill * max(len(sensor_fills), 1))(*sensor_fills)
+        return arr, len(fills), keep, blob, sarr, len(sensor_fills)
 
     def _reset_masked(self, mask: torch.Tensor):
         """``_reset_idx`` for the envs flagged in ``mask`` (``reset_buf``) with no host synchronisation: statistics as

@@ -153,25 +153,39 @@ def test_post_physics_step_rejects_what_it_does_not_cover(device):
     tr = L.MdpTerminationRewardArgs()
     with pytest.raises(ValueError, match="programs required"):
         L.check(L.lib.mdp_post_physics_step(16, None, 0.0, C.byref(tr), None, None, None, L.stream(device)))
+    with pytest.raises(ValueError, match="null reset arguments"):
+        L.check(L.lib.mdp_post_physics_step_with_reset(16, None, 0.0, C.byref(tr), None, None, None, None, L.stream(device)))
+    # the flagged recast covers the same casts as the launch it follows
+    sensor = env.scene["height_scanner"]
+    cast = sensor.fill_post_physics(None, env.physics_dt)
+    with pytest.raises(NotImplementedError, match="vertical-ray"):
+        L.check(L.lib.mdp_raycaster_update_flagged(16, C.byref(cast), None, L.stream(device)))
 
 
-@pytest.mark.parametrize("name,mode", (("anymal_d_flat", True), ("anymal_d_flat", "masked"),
-                                       ("anymal_c_rough", True), ("anymal_c_rough", "masked")))
-def test_auto_reset_inside_the_step(device, name, mode):
+@pytest.mark.parametrize("name,mode,single_launch",
+                         (("anymal_d_flat", True, False), ("anymal_d_flat", "masked", False),
+                          ("anymal_c_rough", True, False), ("anymal_c_rough", "masked", False),
+                          ("anymal_c_rough", "masked", True), ("anymal_d_rough", "masked", True)))
+def test_auto_reset_inside_the_step(device, name, mode, single_launch):
     """ManagerBasedRLEnv.step with its reset branch (manager_based_rl_env.py:214-229, 346-391; events and curriculum
     are physics-side and out of scope): envs start close to their time limit, so every step resets some of them --
     LSTM states, contact-sensor and ray-caster bookkeeping, action buffers, episode sums, command metrics / counter /
     resampling, episode counter.  ``True`` is the reference's id-list path (nonzero() on the host), ``"masked"`` the
-    sync-free one (mdp_masked_fill + masked command kernel); both must reproduce the oracle, statistics included."""
+    sync-free one (mdp_masked_fill + masked command kernel); both must reproduce the oracle, statistics included.
+    ``single_launch``: the reset branch runs inside mdp_post_physics_step_with_reset (statistics accumulated by the
+    kernel), followed by the ray caster's own reset + recast of the flagged envs."""
     import torch
 
     from isaaclab_amd.envs.synthetic import make_velocity_env
     from oracle.harness import replay_oracle
 
-    n, steps = 96, 8
+    n, steps = (203 if name == "anymal_d_rough" else 96), 8      # 203: ragged last manager block
     kw = dict(small_terrain=True) if "rough" in name else {}
+    if single_launch:
+        kw["mesh_accel"] = "grid"
     env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=31, **kw)
     env.auto_reset = mode
+    env.observation_manager.persistent_output = single_launch
     g = torch.Generator().manual_seed(5)
     start = env.max_episode_length - torch.randint(1, steps + 3, (n,), generator=g)
     env.episode_length_buf.copy_(start)
@@ -196,3 +210,60 @@ def test_auto_reset_inside_the_step(device, name, mode):
             np.testing.assert_allclose(logs[t][key], exp, rtol=1e-4, atol=1e-6, err_msg=f"{key} step {t}")
             checked += 1
     assert checked > 0
+    assert getattr(env, "_single_launch_steps", 0) == (steps - 1 if single_launch else 0)
+    if "rough" in name:
+        # ray-caster bookkeeping after the run (reset envs: timestamps back to 0, recast in the same step)
+        from oracle.harness import build_oracle, oracle_step
+
+        orc = build_oracle(rec)
+        orc.episode_length[:] = start.numpy()
+        for k in range(steps):
+            oracle_step(orc, rec, k, auto_reset=True)
+        sensor = env.scene["height_scanner"]
+        assert_close(to_np(sensor._timestamp), orc.rc_ts, rtol=1e-6, atol=1e-7)
+        assert_close(to_np(sensor._timestamp_last_update), orc.rc_last, rtol=1e-6, atol=1e-7)
+        assert_close(to_np(sensor._is_outdated).astype(bool), orc.rc_outdated)
+        assert_close(to_np(sensor.data.ray_hits_w), orc.ray_hits, rtol=1e-5, atol=1e-5)
+
+
+def test_raycaster_update_flagged(device):
+    """mdp_raycaster_update_flagged = RayCaster.reset(mask) + the lazy recast: flagged envs get zeroed timestamps and are
+    cast at the current pose, outdated envs are cast without a reset, every other env keeps hits, pose and timestamps
+    (the sensor pose moved in between, so a cast that should not have happened would show)."""
+    import ctypes as C
+
+    import torch
+
+    from isaaclab_amd import _lib as L
+
+    n = 40
+    env, rec, outs = run_env("anymal_d_rough", n, 3, device, seed=23, small_terrain=True, persistent=True, mesh_accel="grid")
+    sensor = env.scene["height_scanner"]
+    torch.cuda.synchronize()
+    hits0, ts0, last0 = sensor.data.ray_hits_w.clone(), sensor._timestamp.clone(), sensor._timestamp_last_update.clone()
+    assert not sensor._is_outdated.any() and (ts0 > 0).all()
+    pose = sensor._view.get_root_transforms()
+    pose[:, 0] += 0.37                                     # the robots moved since the last cast
+    mask = torch.zeros(n, dtype=torch.uint8, device=device)
+    mask[[3, 17, 39]] = 1
+    sensor._is_outdated[8] = True                          # outdated for another reason: cast, but not reset
+    cast = sensor.fill_post_physics(None, env.physics_dt)
+    L.check(L.lib.mdp_raycaster_update_flagged(n, C.byref(cast), mask.data_ptr(), L.stream(device)))
+    torch.cuda.synchronize()
+    touched = torch.zeros(n, dtype=torch.bool, device=device)
+    touched[[3, 17, 39, 8]] = True
+    assert not sensor._is_outdated.any()
+    assert torch.equal(sensor.data.ray_hits_w[~touched], hits0[~touched])
+    assert torch.equal(sensor._timestamp[~touched], ts0[~touched]) and torch.equal(sensor._timestamp_last_update[~touched], last0[~touched])
+    assert (sensor._timestamp[[3, 17, 39]] == 0).all() and (sensor._timestamp_last_update[[3, 17, 39]] == 0).all()
+    assert sensor._timestamp[8] == ts0[8] and sensor._timestamp_last_update[8] == ts0[8]
+    moved = (sensor.data.ray_hits_w[touched][..., 0] - hits0[touched][..., 0])
+    assert torch.allclose(moved[torch.isfinite(moved)], torch.full_like(moved[torch.isfinite(moved)], 0.37), atol=1e-4)
+    # the same envs through the regular update (all flagged outdated): identical hits for the four, new hits for the rest
+    got = sensor.data.ray_hits_w.clone()
+    sensor._is_outdated.fill_(True)
+    sensor._update_outdated_buffers(from_physics=True)
+    torch.cuda.synchronize()
+    a, b = got[touched], sensor.data.ray_hits_w[touched]
+    assert torch.equal(torch.nan_to_num(a, posinf=1e30), torch.nan_to_num(b, posinf=1e30))
+    assert not torch.equal(sensor.data.ray_hits_w[~touched], hits0[~touched])

@@ -56,6 +56,9 @@ def cast_phases(st):
 def main():
     env, rec = make_velocity_env("anymal_c_rough", num_envs=4096, device="cuda:0", steps=8, seed=5, inject_random=False)
     env.observation_manager.persistent_output = True
+    reset = os.environ.get("STAMPS_RESET", "0") == "1"      # the launch with the reset branch in it
+    if reset:
+        env.auto_reset = "masked"
     acts = rec.actions.to("cuda:0")
     for k in range(8):
         env.step(acts[k % acts.shape[0]])
@@ -71,10 +74,24 @@ def main():
     for rep in range(3):
         buf.zero_()
         torch.cuda.synchronize()
-        env._post_physics_single_launch()
+        env._post_physics_single_launch(reset=reset)
         torch.cuda.synchronize()
         if rep == 2:
             show("k_post_physics", buf, {2: "managers", 1: "cast"}, {2: 5, 1: 1})
+            if reset:
+                st = buf.cpu().numpy().astype(np.int64)
+                m = st[(st[:, 0] != 0) & (st[:, 7] == 2)]
+                last = m[np.argmax(m[:, 5])]
+                t0 = st[st[:, 0] != 0][:, 0].min()
+                d23 = (m[:, 3] - m[:, 2]) / 100.0
+                dones = env.termination_manager._dones_buf.cpu().numpy().astype(np.int64)
+                per_block = np.add.reduceat(dones, np.arange(0, len(dones), 24))[: len(m)]   # MDP_POST_ENVS = 24
+                print("           rewards+reset phase: blocks without done envs med %.2f max %.2f | with done envs (%d blocks) med %.2f max %.2f"
+                      % (np.median(d23[per_block == 0]), d23[per_block == 0].max(), int((per_block > 0).sum()),
+                         np.median(d23[per_block > 0]) if (per_block > 0).any() else 0.0,
+                         d23[per_block > 0].max() if (per_block > 0).any() else 0.0))
+                print("           manager block that ends last: stamps (us) " +
+                      "  ".join("%.2f" % ((last[k] - t0) / 100.0) for k in (0, 1, 2, 3, 4, 6, 5)) + "   (6 = before the log reduction)")
             cast_phases(buf)
             it = full[8192 * 8:].cpu().numpy().reshape(4096, 187)
             dis, n, batches = it // 1000, (it % 1000) // 10, it % 10
