@@ -717,6 +717,76 @@ int mdp_post_physics_step_with_reset(int num_envs, const mdp_scene_update_t* upd
 int mdp_raycaster_update_flagged(int num_envs, const mdp_raycaster_update_args_t* cast, const uint8_t* reset_mask,
                                  void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Event terms of the "reset" and "interval" modes.  The reference calls them with an id list taken
+ * from nonzero() on the host (manager_based_rl_env.py:214, event_manager.py:218); here the selection is `env_mask`
+ * (device, num_envs bytes, NULL = every env, i.e. env_ids=None) and nothing synchronises.  Each call writes what the
+ * reference's asset.write_*_to_sim writes: the data buffers of the asset AND the physics buffers (set_root_transforms
+ * / set_root_velocities / set_dof_positions / set_dof_velocities with indices).
+ * Random numbers: `injected_u` (device, uniforms in [0,1), row e = the numbers env e consumes, in the order the
+ * reference draws them) or `rng_state` (device, 1 + num_envs words: seed, then one epoch per env, advanced when that
+ * env draws).  Ranges travel as lo / scale with sample = u * scale + lo (sample_uniform, math.py:1331): scale is
+ * fp32(hi) - fp32(lo) for the dict ranges (tensors in the reference) and fp32(hi - lo) for the tuple ranges (Python
+ * floats in the reference).
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {                       /* reset_root_state_uniform, events.py:638-680 */
+    const uint8_t* env_mask;
+    const float* default_root_state;   /* (N,13) */
+    const float* env_origins;          /* (N,3) */
+    float pose_lo[6], pose_scale[6];   /* x, y, z, roll, pitch, yaw */
+    float vel_lo[6], vel_scale[6];
+    const float* injected_u;           /* (N,12): 6 pose then 6 velocity uniforms */
+    uint64_t* rng_state;
+    float* root_state_w;               /* (N,13) data buffer (articulation.py:332, 417) */
+    float* sim_root_transforms;        /* (N,7) x, y, z, qx, qy, qz, qw (articulation.py:334-341) */
+    float* sim_root_velocities;        /* (N,6) (articulation.py:420) */
+    float* body_acc_w;                 /* (N,B,6), zeroed for the envs (articulation.py:418), may be NULL */
+    int32_t num_bodies;
+    int32_t pad0;
+} mdp_event_root_state_t;
+int mdp_event_reset_root_state_uniform(int num_envs, const mdp_event_root_state_t* args, void* stream);
+
+typedef struct {                       /* reset_joints_by_scale / _by_offset, events.py:802-866 */
+    const uint8_t* env_mask;
+    int32_t num_joints;
+    int32_t mode;                      /* 0 = by scale, 1 = by offset */
+    const float* default_joint_pos;    /* (N,J) */
+    const float* default_joint_vel;    /* (N,J) */
+    float pos_lo, pos_scale, vel_lo, vel_scale;
+    const float* soft_joint_pos_limits;/* (N,J,2) */
+    const float* soft_joint_vel_limits;/* (N,J) */
+    const float* injected_u;           /* (N,2J): J position then J velocity uniforms */
+    uint64_t* rng_state;
+    float* joint_pos;                  /* (N,J) data buffers (articulation.py:498-501) */
+    float* joint_vel;
+    float* prev_joint_vel;
+    float* joint_acc;
+    float* sim_dof_positions;          /* (N, ld_sim) physics buffers (articulation.py:507-508) */
+    float* sim_dof_velocities;
+    int32_t ld_sim;
+    int32_t pad0;
+} mdp_event_joints_t;
+int mdp_event_reset_joints(int num_envs, const mdp_event_joints_t* args, void* stream);
+
+typedef struct {                       /* push_by_setting_velocity, events.py:610-635 */
+    const uint8_t* env_mask;
+    float vel_lo[6], vel_scale[6];
+    const float* injected_u;           /* (N,6) */
+    uint64_t* rng_state;
+    float* root_state_w;               /* (N,13): columns 7..12 are read and written */
+    float* sim_root_velocities;        /* (N,6) */
+    float* body_acc_w;                 /* (N,B,6) or NULL */
+    int32_t num_bodies;
+    int32_t pad0;
+} mdp_event_push_t;
+int mdp_event_push_by_setting_velocity(int num_envs, const mdp_event_push_t* args, void* stream);
+
+/* EventManager.apply(mode="interval") for one term (event_manager.py:199-225): time_left -= dt; where it drops below
+ * 1e-6 the timer is resampled (u * scale + lo) and trigger_mask = 1, else 0.  is_global_time: `time_left` is ONE
+ * word shared by all envs (and injected_u / rng_state hold one uniform / one epoch). */
+int mdp_event_interval_tick(int num_envs, float* time_left, float dt, float lo, float scale, int is_global_time,
+                            const float* injected_u, uint64_t* rng_state, uint8_t* trigger_mask, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

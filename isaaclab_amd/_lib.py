@@ -152,6 +152,38 @@ class MdpPostResetArgs(C.Structure):
                 ("log_sums", C.c_void_p), ("log", C.c_void_p)]
 
 
+class MdpEventRootState(C.Structure):
+    """Mirror of ``mdp_event_root_state_t``."""
+
+    _fields_ = [("env_mask", C.c_void_p), ("default_root_state", C.c_void_p), ("env_origins", C.c_void_p),
+                ("pose_lo", C.c_float * 6), ("pose_scale", C.c_float * 6), ("vel_lo", C.c_float * 6),
+                ("vel_scale", C.c_float * 6), ("injected_u", C.c_void_p), ("rng_state", C.c_void_p),
+                ("root_state_w", C.c_void_p), ("sim_root_transforms", C.c_void_p), ("sim_root_velocities", C.c_void_p),
+                ("body_acc_w", C.c_void_p), ("num_bodies", C.c_int32), ("pad0", C.c_int32)]
+
+
+class MdpEventJoints(C.Structure):
+    """Mirror of ``mdp_event_joints_t``."""
+
+    _fields_ = [("env_mask", C.c_void_p), ("num_joints", C.c_int32), ("mode", C.c_int32),
+                ("default_joint_pos", C.c_void_p), ("default_joint_vel", C.c_void_p),
+                ("pos_lo", C.c_float), ("pos_scale", C.c_float), ("vel_lo", C.c_float), ("vel_scale", C.c_float),
+                ("soft_joint_pos_limits", C.c_void_p), ("soft_joint_vel_limits", C.c_void_p),
+                ("injected_u", C.c_void_p), ("rng_state", C.c_void_p),
+                ("joint_pos", C.c_void_p), ("joint_vel", C.c_void_p), ("prev_joint_vel", C.c_void_p),
+                ("joint_acc", C.c_void_p), ("sim_dof_positions", C.c_void_p), ("sim_dof_velocities", C.c_void_p),
+                ("ld_sim", C.c_int32), ("pad0", C.c_int32)]
+
+
+class MdpEventPush(C.Structure):
+    """Mirror of ``mdp_event_push_t``."""
+
+    _fields_ = [("env_mask", C.c_void_p), ("vel_lo", C.c_float * 6), ("vel_scale", C.c_float * 6),
+                ("injected_u", C.c_void_p), ("rng_state", C.c_void_p), ("root_state_w", C.c_void_p),
+                ("sim_root_velocities", C.c_void_p), ("body_acc_w", C.c_void_p), ("num_bodies", C.c_int32),
+                ("pad0", C.c_int32)]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -1,0 +1,208 @@
+// Event terms of the reset / interval modes as masked kernels: the reference calls them with
+// an id list that comes from nonzero() on the host; here the selection is a byte mask on the device and nothing
+// synchronises.  Reference arithmetic: LAB/envs/mdp/events.py:610-866, LAB/managers/event_manager.py:199-225,
+// LAB/assets/articulation/articulation.py:316-341, 400-420, 472-508, LAB/utils/math.py:252-278, 463-499, 1331.
+//
+// One thread per env: an env that is not selected costs one byte read.  Random numbers are either injected (tests:
+// the same uniforms go to the oracle) or drawn from Philox keyed by (seed, per-env epoch): the epoch word of an env
+// advances only when that env draws, so a launch never races on a shared counter and a captured graph keeps drawing
+// new numbers.
+#include "mdp_device.hpp"
+#include "mdp_host.hpp"
+
+using namespace mdp;
+
+namespace {
+
+// k-th uniform of env e: injected row or Philox(seed, epoch, stream, e * 4 + k / 4)
+struct Uniforms {
+    const float* inj;
+    int per_env;
+    uint64_t seed, epoch;
+    uint32_t stream;
+    int e;
+    __device__ __forceinline__ float operator()(int k) const {
+        if (inj) return inj[(int64_t)e * per_env + k];
+        U4 r = rng4(seed, epoch, stream, (uint64_t)e * 64u + (uint64_t)(k >> 2));
+        uint32_t w = (k & 3) == 0 ? r.x : ((k & 3) == 1 ? r.y : ((k & 3) == 2 ? r.z : r.w));
+        return u01(w);
+    }
+};
+
+__device__ __forceinline__ Uniforms uniforms_for(const float* inj, int per_env, uint64_t* rng_state, uint32_t stream, int e) {
+    Uniforms u{inj, per_env, 0, 0, stream, e};
+    if (!inj && rng_state) {
+        u.seed = rng_state[0];
+        u.epoch = rng_state[1 + e];
+        rng_state[1 + e] = u.epoch + 1;
+    }
+    return u;
+}
+
+// math.py:252-278
+__device__ __forceinline__ Q4 quat_from_euler_xyz(float roll, float pitch, float yaw) {
+    float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f);
+    float cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
+    float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
+    return Q4{cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp,
+              sy * cr * cp - cy * sr * sp};
+}
+
+__device__ __forceinline__ void zero_body_acc(float* body_acc_w, int num_bodies, int e) {
+    if (!body_acc_w) return;
+    float* p = body_acc_w + (int64_t)e * num_bodies * 6;
+    for (int i = 0; i < num_bodies * 6; ++i) p[i] = 0.0f;      // articulation.py:418
+}
+
+// events.py:638-680 + articulation.py:316-341, 400-420
+__global__ void k_reset_root_state_uniform(int N, mdp_event_root_state_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || (a.env_mask && !a.env_mask[e])) return;
+    Uniforms u = uniforms_for(a.injected_u, 12, a.rng_state, 0x45525354u, e);
+    const float* d = a.default_root_state + (int64_t)e * 13;
+    float s[6];
+    for (int k = 0; k < 6; ++k) s[k] = u(k) * a.pose_scale[k] + a.pose_lo[k];
+    V3 pos{(d[0] + a.env_origins[3 * e + 0]) + s[0], (d[1] + a.env_origins[3 * e + 1]) + s[1],
+           (d[2] + a.env_origins[3 * e + 2]) + s[2]};
+    Q4 q = quat_mul(ld4(d + 3), quat_from_euler_xyz(s[3], s[4], s[5]));
+    float v[6];
+    for (int k = 0; k < 6; ++k) v[k] = d[7 + k] + (u(6 + k) * a.vel_scale[k] + a.vel_lo[k]);
+    float* r = a.root_state_w + (int64_t)e * 13;
+    st3(r, pos);
+    st4(r + 3, q);
+    for (int k = 0; k < 6; ++k) r[7 + k] = v[k];
+    float* t = a.sim_root_transforms + (int64_t)e * 7;         // (x, y, z, qx, qy, qz, qw)
+    st3(t, pos);
+    t[3] = q.x; t[4] = q.y; t[5] = q.z; t[6] = q.w;
+    float* sv = a.sim_root_velocities + (int64_t)e * 6;
+    for (int k = 0; k < 6; ++k) sv[k] = v[k];
+    zero_body_acc(a.body_acc_w, a.num_bodies, e);
+}
+
+// events.py:802-866 + articulation.py:472-508
+__global__ void k_reset_joints(int N, mdp_event_joints_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || (a.env_mask && !a.env_mask[e])) return;
+    const int J = a.num_joints;
+    Uniforms u = uniforms_for(a.injected_u, 2 * J, a.rng_state, 0x454a4e54u, e);
+    for (int j = 0; j < J; ++j) {
+        const int64_t i = (int64_t)e * J + j;
+        float sp = u(j) * a.pos_scale + a.pos_lo;
+        float sv = u(J + j) * a.vel_scale + a.vel_lo;
+        float q = a.mode == 0 ? a.default_joint_pos[i] * sp : a.default_joint_pos[i] + sp;
+        float qd = a.mode == 0 ? a.default_joint_vel[i] * sv : a.default_joint_vel[i] + sv;
+        q = tclamp(q, a.soft_joint_pos_limits[2 * i], a.soft_joint_pos_limits[2 * i + 1]);
+        float vl = a.soft_joint_vel_limits[i];
+        qd = tclamp(qd, -vl, vl);
+        a.joint_pos[i] = q;
+        a.joint_vel[i] = qd;
+        a.prev_joint_vel[i] = qd;
+        a.joint_acc[i] = 0.0f;
+        a.sim_dof_positions[(int64_t)e * a.ld_sim + j] = q;
+        a.sim_dof_velocities[(int64_t)e * a.ld_sim + j] = qd;
+    }
+}
+
+// events.py:610-635 + articulation.py:400-420
+__global__ void k_push_by_setting_velocity(int N, mdp_event_push_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || (a.env_mask && !a.env_mask[e])) return;
+    Uniforms u = uniforms_for(a.injected_u, 6, a.rng_state, 0x45505348u, e);
+    float* r = a.root_state_w + (int64_t)e * 13 + 7;
+    float* sv = a.sim_root_velocities + (int64_t)e * 6;
+    for (int k = 0; k < 6; ++k) {
+        float v = r[k] + (u(k) * a.vel_scale[k] + a.vel_lo[k]);
+        r[k] = v;
+        sv[k] = v;
+    }
+    zero_body_acc(a.body_acc_w, a.num_bodies, e);
+}
+
+// event_manager.py:203-225, per-env timers
+__global__ void k_interval_tick(int N, float* __restrict__ time_left, float dt, float lo, float scale,
+                                const float* __restrict__ inj, uint64_t* rng_state, uint8_t* __restrict__ trigger) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N) return;
+    float t = time_left[e] - dt;
+    bool fire = t < 1e-6f;
+    if (fire) {
+        Uniforms u = uniforms_for(inj, 1, rng_state, 0x45495654u, e);
+        t = u(0) * scale + lo;
+    }
+    time_left[e] = t;
+    trigger[e] = fire ? 1 : 0;
+}
+
+// event_manager.py:209-216, one timer for all envs (is_global_time): a single block, the decision is taken once
+__global__ void k_interval_tick_global(int N, float* time_left, float dt, float lo, float scale, const float* inj,
+                                       uint64_t* rng_state, uint8_t* __restrict__ trigger) {
+    __shared__ int s_fire;
+    if (threadIdx.x == 0) {
+        float t = time_left[0] - dt;
+        bool fire = t < 1e-6f;
+        if (fire) {
+            Uniforms u = uniforms_for(inj, 1, rng_state, 0x45495647u, 0);
+            t = u(0) * scale + lo;
+        }
+        time_left[0] = t;
+        s_fire = fire ? 1 : 0;
+    }
+    __syncthreads();
+    const uint8_t f = (uint8_t)s_fire;
+    for (int e = threadIdx.x; e < N; e += blockDim.x) trigger[e] = f;
+}
+
+}  // namespace
+
+extern "C" int mdp_event_reset_root_state_uniform(int num_envs, const mdp_event_root_state_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->default_root_state && a->env_origins && a->root_state_w && a->sim_root_transforms &&
+                    a->sim_root_velocities, "null pointer");
+    MDP_REQUIRE(a->injected_u || a->rng_state, "need rng_state or injected_u");
+    MDP_REQUIRE(!a->body_acc_w || a->num_bodies > 0, "body_acc_w without num_bodies");
+    if (num_envs <= 0) return MDP_OK;
+    hipLaunchKernelGGL(k_reset_root_state_uniform, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_event_reset_joints(int num_envs, const mdp_event_joints_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->mode == 0 || a->mode == 1, "mode must be 0 (by scale) or 1 (by offset)");
+    MDP_REQUIRE(a->num_joints > 0 && a->num_joints <= 128, "num_joints out of range");
+    MDP_REQUIRE(a->default_joint_pos && a->default_joint_vel && a->soft_joint_pos_limits && a->soft_joint_vel_limits &&
+                    a->joint_pos && a->joint_vel && a->prev_joint_vel && a->joint_acc && a->sim_dof_positions &&
+                    a->sim_dof_velocities, "null pointer");
+    MDP_REQUIRE(a->ld_sim >= a->num_joints, "ld_sim < num_joints");
+    MDP_REQUIRE(a->injected_u || a->rng_state, "need rng_state or injected_u");
+    if (num_envs <= 0) return MDP_OK;
+    hipLaunchKernelGGL(k_reset_joints, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_event_push_by_setting_velocity(int num_envs, const mdp_event_push_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->root_state_w && a->sim_root_velocities, "null pointer");
+    MDP_REQUIRE(a->injected_u || a->rng_state, "need rng_state or injected_u");
+    MDP_REQUIRE(!a->body_acc_w || a->num_bodies > 0, "body_acc_w without num_bodies");
+    if (num_envs <= 0) return MDP_OK;
+    hipLaunchKernelGGL(k_push_by_setting_velocity, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_event_interval_tick(int num_envs, float* time_left, float dt, float lo, float scale, int is_global_time,
+                                       const float* injected_u, uint64_t* rng_state, uint8_t* trigger_mask, void* stream) {
+    MDP_REQUIRE(time_left && trigger_mask, "null pointer");
+    MDP_REQUIRE(injected_u || rng_state, "need rng_state or injected_u");
+    if (num_envs <= 0) return MDP_OK;
+    if (is_global_time)
+        hipLaunchKernelGGL(k_interval_tick_global, dim3(1), dim3(1024), 0, as_stream(stream), num_envs, time_left, dt, lo,
+                           scale, injected_u, rng_state, trigger_mask);
+    else
+        hipLaunchKernelGGL(k_interval_tick, dim3(grid_for(num_envs, 256)), dim3(256), 0, as_stream(stream), num_envs,
+                           time_left, dt, lo, scale, injected_u, rng_state, trigger_mask);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}

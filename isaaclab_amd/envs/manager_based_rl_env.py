@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from ..assets import Articulation, SyntheticPhysicsView
-from ..managers import ActionManager, CommandManager, ObservationManager, RewardManager, TerminationManager
+from ..managers import (ActionManager, CommandManager, EventManager, ObservationManager, RewardManager,
+                        TerminationManager)
 from ..scene import InteractiveScene
 from ..sensors import ContactSensor, RayCaster
 from ..terrains import SyntheticTerrain, SyntheticTerrainCfg
@@ -73,6 +74,11 @@ class ManagerBasedRLEnv:
         self.termination_manager = TerminationManager(cfg.terminations, self)
         self.observation_manager = ObservationManager(cfg.observations, self, seed=getattr(cfg, "seed", None))
         self.reward_manager = RewardManager(cfg.rewards, self)
+        # reset / interval event terms (manager_based_env.py:131-133); tasks without an ``events`` cfg have none
+        self.seed = getattr(cfg, "seed", None)
+        self.event_uniforms: dict[str, torch.Tensor] = {}     # tests: injected random numbers per event function
+        self.event_manager = EventManager(getattr(cfg, "events", None), self)
+        self._sim_step_counter = 0
         self.obs_buf = None
         self.reward_buf = None
         self.reset_buf = None
@@ -111,11 +117,16 @@ class ManagerBasedRLEnv:
         # sensor-owned observation columns (height scan) come from the cast kernel, on its own stream
         split = concurrent and om.can_split_sensor_terms()
         early_cast = split and self.scene.fused_update and len(om.scan_sensors()) > 0
+        has_events = any(m in self.event_manager.available_modes for m in ("reset", "interval"))
+        if has_events:
+            # event terms write the robot state between rewards and observations: the stages run one after the other
+            split = early_cast = concurrent = False
         if masked and not (early_cast and self.single_launch_post_physics):
             split = early_cast = concurrent = False   # resets sit between rewards and commands: serial launches below
         self.action_manager.apply_action()
         self.scene.write_data_to_sim(joint_action=deferred)
         for k in range(decimation):
+            self._sim_step_counter += 1
             self.physics.advance()                      # sim.step(render=False): synthetic / replayed
             if k + 1 < decimation:
                 # scene.update(k), apply_action(k+1), write_data_to_sim(k+1): nothing steps physics between them, so
@@ -177,6 +188,8 @@ class ManagerBasedRLEnv:
                 if len(reset_env_ids) > 0:
                     self._reset_idx(reset_env_ids)
             self.command_manager.compute(dt=self.step_dt)
+            if "interval" in self.event_manager.available_modes:
+                self.event_manager.apply(mode="interval", dt=self.step_dt)      # manager_based_rl_env.py:233-235
             self.obs_buf = self.observation_manager.compute()
         self.reset_terminated = self.termination_manager.terminated
         self.reset_time_outs = self.termination_manager.time_outs
@@ -428,14 +441,21 @@ class ManagerBasedRLEnv:
             log["Episode_Termination/" + name] = done_counts[i]
         self.extras["log"] = log
         L.check(L.lib.mdp_masked_fill(arr, count, mask.data_ptr(), self.num_envs, L.stream(self.device)))
+        if "reset" in self.event_manager.available_modes:                      # manager_based_rl_env.py:357-359
+            self.event_manager.apply(mode="reset", env_ids=mask,
+                                     global_env_step_count=self._sim_step_counter // self.cfg.decimation)
+        self.event_manager.reset(mask)
         for term in self._reset_cmd_terms:
             term._launch(0.0, mask)           # CommandTerm.reset: resample (+ counter) for the flagged envs
 
     def _reset_idx(self, env_ids):
         """manager_based_rl_env.py:346-391 without events / curriculum (out of scope)."""
         self.scene.reset(env_ids)
+        if "reset" in self.event_manager.available_modes:
+            self.event_manager.apply(mode="reset", env_ids=env_ids,
+                                     global_env_step_count=self._sim_step_counter // self.cfg.decimation)
         self.extras["log"] = dict()
         for manager in (self.observation_manager, self.action_manager, self.reward_manager,
-                        self.command_manager, self.termination_manager):
+                        self.command_manager, self.event_manager, self.termination_manager):
             self.extras["log"].update(manager.reset(env_ids))
         self.episode_length_buf[env_ids] = 0

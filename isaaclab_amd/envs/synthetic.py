@@ -98,6 +98,9 @@ class Recording:
         self.network = None                           # actuator net module (anymal_c_rough)
         self._dev_noise: dict[str, torch.Tensor] = {}
         self._dev_cmd: torch.Tensor | None = None
+        self.events: dict | None = None               # event cfg values + initial state (default root state, push timers)
+        self.event_uniforms: dict[str, torch.Tensor] = {}   # event function name / "interval" -> host (steps, N, k)
+        self._dev_events: dict[str, torch.Tensor] = {}
 
     def field(self, name: str, t: int) -> np.ndarray:
         o, s, shape = self.fields[name]
@@ -109,6 +112,8 @@ class Recording:
             dev.copy_(self.obs_noise[name][t], non_blocking=True)
         if self._dev_cmd is not None:
             self._dev_cmd.copy_(self.cmd_uniforms[t], non_blocking=True)
+        for name, dev in self._dev_events.items():
+            dev.copy_(self.event_uniforms[name][t], non_blocking=True)
 
 
 def synthetic_anydrive_lstm(seed: int = 303, hidden: int = 8, layers: int = 2):
@@ -148,7 +153,7 @@ def _env_cfg(name: str, num_envs: int, network=None):
 
 def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: int = 8, seed: int = 0,
                       small_terrain: bool = False, inject_random: bool = True, network=None, terrain=None,
-                      mesh_accel: str = "auto"):
+                      mesh_accel: str = "auto", events: bool = False):
     """Builds a velocity-task env over a replayed synthetic physics feed.  Returns ``(env, recording)``.
 
     ``inject_random=True`` replaces the device generators of the command term and of the observation noise by
@@ -160,6 +165,10 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
     if name == "anymal_c_rough" and network is None:
         network = synthetic_anydrive_lstm()
     cfg = _env_cfg(name, num_envs, network)
+    if events:                              # reset + interval event terms of the task (off in the headline workload)
+        from ..tasks.velocity.velocity_env_cfg import EventCfg
+
+        cfg.events = EventCfg()
     rough = cfg.scene.height_scanner is not None
     if terrain is None and rough:
         gen = TerrainGeneratorCfg(num_rows=2, num_cols=5) if small_terrain else TerrainGeneratorCfg()
@@ -201,4 +210,35 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
             dev = torch.zeros((num_envs, dim), dtype=torch.float32, device=device)
             tcfg._injected_noise = dev
             rec._dev_noise[tname] = dev
+    if events:
+        # a default root state that exercises the whole pose arithmetic, push timers that fire within the first steps
+        rng = np.random.RandomState(seed + 7919)
+        d = np.zeros((num_envs, 13), np.float32)
+        d[:, 2] = 0.6
+        ang = rng.uniform(-0.3, 0.3, size=(num_envs, 3)).astype(np.float32)
+        cr, sr, cp, sp, cy, sy = (f(ang[:, k] * 0.5) for k in range(3) for f in (np.cos, np.sin))
+        quat = np.stack([cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp,
+                         sy * cr * cp - cy * sr * sp], axis=1)
+        d[:, 3:7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+        d[:, 7:13] = rng.uniform(-0.05, 0.05, size=(num_envs, 6)).astype(np.float32)
+        robot.data.default_root_state.copy_(torch.from_numpy(d))
+        push0 = rng.uniform(0.0, 0.12, size=num_envs).astype(np.float32)
+        env.event_manager._interval_term_time_left[0].copy_(torch.from_numpy(push0))
+        ecfg = cfg.events
+        rec.events = dict(default_root_state=d, push_time_left0=push0,
+                          reset_base=dict(ecfg.reset_base.params), reset_robot_joints=dict(ecfg.reset_robot_joints.params),
+                          push_robot=dict(velocity_range=ecfg.push_robot.params["velocity_range"],
+                                          interval_range_s=ecfg.push_robot.interval_range_s))
+        if inject_random:
+            j = robot.num_joints
+            widths = {"reset_root_state_uniform": 12, "reset_joints_by_scale": 2 * j, "push_by_setting_velocity": 6}
+            for fname, w in widths.items():
+                rec.event_uniforms[fname] = torch.from_numpy(rng.uniform(size=(steps, num_envs, w)).astype(np.float32))
+                dev = torch.zeros((num_envs, w), dtype=torch.float32, device=device)
+                env.event_uniforms[fname] = dev
+                rec._dev_events[fname] = dev
+            rec.event_uniforms["interval"] = torch.from_numpy(rng.uniform(size=(steps, num_envs)).astype(np.float32))
+            dev = torch.zeros(num_envs, dtype=torch.float32, device=device)
+            env.event_manager.interval_uniforms[0] = dev
+            rec._dev_events["interval"] = dev
     return env, rec

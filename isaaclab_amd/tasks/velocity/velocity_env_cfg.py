@@ -7,6 +7,7 @@ import math
 from dataclasses import MISSING
 
 from ...assets import ArticulationCfg
+from ...managers import EventTermCfg as EventTerm
 from ...managers import ObservationGroupCfg as ObsGroup
 from ...managers import ObservationTermCfg as ObsTerm
 from ...managers import RewardTermCfg as RewTerm
@@ -123,6 +124,35 @@ class TerminationsCfg:
 
 
 @configclass
+class EventCfg:
+    """velocity_env_cfg.py:150-218 without the terms that only touch physics properties (startup material / mass
+    randomisation, the zero-range external wrench): what is left writes robot state the MDP terms read."""
+
+    reset_base = EventTerm(
+        func=mdp.reset_root_state_uniform,
+        mode="reset",
+        params={
+            "pose_range": {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "yaw": (-3.14, 3.14)},
+            "velocity_range": {
+                "x": (-0.5, 0.5), "y": (-0.5, 0.5), "z": (-0.5, 0.5),
+                "roll": (-0.5, 0.5), "pitch": (-0.5, 0.5), "yaw": (-0.5, 0.5),
+            },
+        },
+    )
+    reset_robot_joints = EventTerm(
+        func=mdp.reset_joints_by_scale,
+        mode="reset",
+        params={"position_range": (0.5, 1.5), "velocity_range": (0.0, 0.0)},
+    )
+    push_robot = EventTerm(
+        func=mdp.push_by_setting_velocity,
+        mode="interval",
+        interval_range_s=(10.0, 15.0),
+        params={"velocity_range": {"x": (-0.5, 0.5), "y": (-0.5, 0.5)}},
+    )
+
+
+@configclass
 class SimCfg:
     dt: float = 0.005
     render_interval: int = 1
@@ -136,6 +166,7 @@ class LocomotionVelocityRoughEnvCfg:
     commands: CommandsCfg = CommandsCfg()
     rewards: RewardsCfg = RewardsCfg()
     terminations: TerminationsCfg = TerminationsCfg()
+    events: EventCfg | None = None      # EventCfg(): reset + interval events on the step path
     sim: SimCfg = SimCfg()
     decimation: int = 4
     episode_length_s: float = 20.0

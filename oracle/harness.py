@@ -42,6 +42,8 @@ def build_oracle(rec, threads: int = 0) -> VelocityStepOracle:
         spec = h1_spec(rec.num_envs, rec.env_origins, caster, starts, dirs, threads=threads)
     else:
         raise NotImplementedError(f"no oracle spec for config '{rec.name}'")
+    if getattr(rec, "events", None) is not None:
+        spec["events"] = rec.events
     orc = VelocityStepOracle(spec)
     orc.prime(rec.field("dof_positions", 0), rec.field("dof_velocities", 0))
     return orc
@@ -62,7 +64,8 @@ def oracle_step(orc: VelocityStepOracle, rec, k: int, auto_reset: bool = False):
     frames = [frame_dict(rec, 1 + k * d + i) for i in range(d)]
     cmd_u = rec.cmd_uniforms[k].numpy() if rec.cmd_uniforms is not None else None
     noise = {name: u[k].numpy() for name, u in rec.obs_noise.items()} if rec.obs_noise else None
-    return orc.step(rec.actions[k].numpy(), frames, cmd_u, noise, auto_reset=auto_reset)
+    ev_u = {name: u[k].numpy() for name, u in rec.event_uniforms.items()} if getattr(rec, "event_uniforms", None) else None
+    return orc.step(rec.actions[k].numpy(), frames, cmd_u, noise, auto_reset=auto_reset, event_uniforms=ev_u)
 
 
 def replay_oracle(rec, steps: int, threads: int = 0, auto_reset: bool = False, logs: list | None = None,

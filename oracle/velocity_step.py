@@ -62,6 +62,8 @@ class VelocityStepOracle:
             self.rc_last = np.zeros(n, np.float32)
             self.rc_outdated = np.ones(n, bool)
         self._body_state = None
+        if s.get("events") and s["events"].get("push_robot") is not None:
+            self.push_time_left = np.asarray(s["events"]["push_time_left0"], np.float32).copy()
         act = s["actuator"]
         if act["kind"] == "lstm":
             L, H = len(act["lstm_weights"]), act["lstm_weights"][0][1].shape[1]
@@ -117,6 +119,27 @@ class VelocityStepOracle:
         self.rc_last[ids] = self.rc_ts[ids]
         self.rc_outdated[ids] = False
 
+    def _apply_reset_events(self, ids, root, q, qd, eu):
+        """EventManager.apply(mode="reset") of the velocity task (velocity_env_cfg.py:187-210): the writes land in the
+        asset's data buffers (articulation.py:332, 417-418, 498-501) -- here ``root`` / ``q`` / ``qd`` of this step."""
+        from . import events_np as EV
+
+        ev = self.s["events"]
+        if ev.get("reset_base") is not None:
+            pose, vel = EV.reset_root_state_uniform(ev["default_root_state"], self.s["env_origins"], ids,
+                                                    ev["reset_base"]["pose_range"], ev["reset_base"]["velocity_range"],
+                                                    eu["reset_root_state_uniform"])
+            root[ids, :7] = pose
+            root[ids, 7:] = vel
+        if ev.get("reset_robot_joints") is not None:
+            c = ev["reset_robot_joints"]
+            vl = np.full((self.n, self.j), self.s["actuator"]["velocity_limit"], np.float32)
+            jq, jqd = EV.reset_joints(self.default_q, np.zeros_like(self.default_q), self.soft_limits, vl, ids,
+                                      c["position_range"], c["velocity_range"], eu["reset_joints_by_scale"])
+            q[ids], qd[ids] = jq, jqd
+            self.prev_qd[ids] = jqd
+            self.joint_acc[ids] = 0.0
+
     def reset_idx(self, ids, cmd_uniforms):
         """ManagerBasedRLEnv._reset_idx (manager_based_rl_env.py:346-391) without curriculum / events (physics side):
         scene.reset -> manager resets in the reference order -> episode counter.  Returns the ``extras["log"]`` dict."""
@@ -152,8 +175,9 @@ class VelocityStepOracle:
         self.episode_length[ids] = 0
         return log
 
-    def step(self, action, substep_frames, cmd_uniforms=None, obs_noise=None, auto_reset=False):
-        """substep_frames: list of `decimation` dicts {root_state (N,13 wxyz), joint_pos, joint_vel, forces (N,B,3)}."""
+    def step(self, action, substep_frames, cmd_uniforms=None, obs_noise=None, auto_reset=False, event_uniforms=None):
+        """substep_frames: list of `decimation` dicts {root_state (N,13 wxyz), joint_pos, joint_vel, forces (N,B,3)}.
+        ``event_uniforms`` (with spec["events"]): {event function name: (N,k) uniforms, "interval": (N,)}."""
         s = self.s
         self.prev_action = self.action.copy()
         self.action = np.asarray(action, np.float32).copy()
@@ -170,10 +194,14 @@ class VelocityStepOracle:
                 self.rc_ts = (self.rc_ts + F(self.dt)).astype(np.float32)
                 self.rc_outdated |= (self.rc_ts - self.rc_last + F(1e-6)) >= F(s["height_scan"]["update_period"])
         fr = substep_frames[-1]
-        root = fr["root_state"]
+        events = s.get("events")
+        # with events the reset / push terms overwrite rows of the data buffers: work on copies of the frame
+        root = fr["root_state"].copy() if events else fr["root_state"]
+        q_now = fr["joint_pos"].copy() if events else fr["joint_pos"]
+        qd_now = fr["joint_vel"].copy() if events else fr["joint_vel"]
         self._body_state = fr.get("body_state")
         self.episode_length += 1
-        E = self.env_dict(root, fr["joint_pos"], fr["joint_vel"])
+        E = self.env_dict(root, q_now, qd_now)
         # terminations
         vals = [fn(E) for _, fn, _ in s["terminations"]]
         for i, v in enumerate(vals):
@@ -194,9 +222,23 @@ class VelocityStepOracle:
         if auto_reset:
             ids = np.nonzero(self.terminated | self.time_outs)[0]
             if ids.size:
+                if events:      # scene.reset -> reset events -> manager resets (manager_based_rl_env.py:355-359)
+                    self._apply_reset_events(ids, root, q_now, qd_now, event_uniforms)
                 self.log = self.reset_idx(ids, cmd_uniforms)
         self.command.compute(root, self.step_dt, cmd_uniforms)
         E["command"] = self.command.cmd
+        if events and events.get("push_robot") is not None:     # interval events (manager_based_rl_env.py:233-235)
+            from . import events_np as EV
+
+            c = events["push_robot"]
+            fired = EV.interval_tick(self.push_time_left, self.step_dt, c["interval_range_s"], event_uniforms["interval"])
+            if fired.size:
+                root[fired, 7:] = EV.push_by_setting_velocity(root[:, 7:], fired, c["velocity_range"],
+                                                              event_uniforms["push_by_setting_velocity"])
+        if events:
+            # the next write_data_to_sim reads the joint state the reset left in the data buffers
+            self._last_q, self._last_qd = q_now, qd_now
+            E["joint_acc"] = self.joint_acc
         # observations
         if s.get("height_scan") is not None:
             self._raycast(root)

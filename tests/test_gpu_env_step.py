@@ -267,3 +267,99 @@ def test_raycaster_update_flagged(device):
     a, b = got[touched], sensor.data.ray_hits_w[touched]
     assert torch.equal(torch.nan_to_num(a, posinf=1e30), torch.nan_to_num(b, posinf=1e30))
     assert not torch.equal(sensor.data.ray_hits_w[~touched], hits0[~touched])
+
+
+@pytest.mark.parametrize("name,mode", (("anymal_d_flat", True), ("anymal_d_flat", "masked"),
+                                       ("anymal_c_rough", "masked"), ("anymal_d_rough", True)))
+def test_reset_and_interval_events(device, name, mode):
+    """The step with the task's event terms (velocity_env_cfg.py:187-218): reset_root_state_uniform and
+    reset_joints_by_scale for the envs that are done, push_by_setting_velocity when an env's interval timer fires.
+    The events write robot state (root pose / velocity, joint state, zeroed joint_acc) that the command update, the
+    height scan and the observations of the SAME step read -- everything must follow the oracle's restatement, on
+    the id-list path and on the sync-free masked path (device masks, mdp_event_* kernels)."""
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+    from oracle.harness import build_oracle, oracle_step
+
+    n, steps = 64, 8
+    kw = dict(small_terrain=True) if "rough" in name else {}
+    env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=41, events=True, **kw)
+    env.auto_reset = mode
+    g = torch.Generator().manual_seed(6)
+    start = env.max_episode_length - torch.randint(1, steps + 3, (n,), generator=g)
+    env.episode_length_buf.copy_(start)
+    orc = build_oracle(rec)
+    orc.episode_length[:] = start.numpy()
+    robot = env.scene["robot"]
+    pushed = 0
+    for t in range(steps):
+        rec.feed(t)
+        obs, rew, term, trunc, extras = env.step(rec.actions[t].to(device))
+        timers_before = orc.push_time_left.copy()
+        exp = oracle_step(orc, rec, t, auto_reset=True)
+        pushed += int((timers_before - np.float32(env.step_dt) < 1e-6).sum())
+        compare([(to_np(obs["policy"]), to_np(rew), to_np(term), to_np(trunc))], [exp])
+        # the data buffers the events wrote (what the next step's actuator and terms read)
+        assert_close(to_np(robot.data.joint_pos), orc._last_q, rtol=1e-6, atol=1e-6, msg=f"joint_pos step {t}")
+        assert_close(to_np(robot.data.joint_vel), orc._last_qd, rtol=1e-6, atol=1e-6, msg=f"joint_vel step {t}")
+        assert_close(to_np(robot.data._previous_joint_vel), orc.prev_qd, rtol=1e-6, atol=1e-6)
+        assert_close(to_np(env.event_manager._interval_term_time_left[0]), orc.push_time_left, rtol=1e-6, atol=1e-6)
+    assert pushed >= n // 2                                 # the interval timers did fire
+    last = rec.field("dof_positions", steps * rec.decimation)
+    assert np.abs(orc._last_q - last).max() > 0.05           # ... and the last step's resets left their joint state
+
+
+def test_event_terms_with_device_generator(device):
+    """The event kernels with their own generator (per-env Philox epochs): samples stay inside the ranges, differ
+    between envs and between calls, and envs outside the mask are not touched (ids and masks select the same envs)."""
+    import torch
+
+    from isaaclab_amd.envs import mdp
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+
+    n = 256
+    env, rec = make_velocity_env("anymal_d_flat", num_envs=n, device=str(device), steps=2, seed=43, events=True,
+                                 inject_random=False)
+    rec.feed(0)
+    env.step(rec.actions[0].to(device))
+    robot = env.scene["robot"]
+    d = robot.data
+    before = d.root_state_w.clone()
+    ids = torch.arange(0, n, 3, device=device)
+    mask = torch.zeros(n, dtype=torch.bool, device=device)
+    mask[ids] = True
+    rng = dict(pose_range={"x": (-0.5, 0.5), "yaw": (-1.0, 1.0)}, velocity_range={"z": (0.1, 0.2)})
+    mdp.reset_root_state_uniform(env, ids, **rng)
+    first = d.root_state_w.clone()
+    assert torch.equal(first[~mask], before[~mask])
+    default = d.default_root_state
+    dx = first[mask, 0] - (default[mask, 0] + env.scene.env_origins[mask, 0])
+    assert dx.min() >= -0.5 - 1e-5 and dx.max() <= 0.5 + 1e-5 and dx.std() > 0.2
+    assert torch.allclose(first[mask, 1], default[mask, 1] + env.scene.env_origins[mask, 1])
+    vz = first[mask, 9] - default[mask, 9]
+    assert vz.min() >= 0.1 - 1e-6 and vz.max() <= 0.2 + 1e-6
+    assert torch.allclose(first[mask, 3:7].norm(dim=1), torch.ones(int(mask.sum()), device=device), atol=1e-5)
+    view = robot.root_physx_view
+    assert torch.equal(view.get_root_transforms()[mask][:, [6, 3, 4, 5]], first[mask, 3:7])       # xyzw in the sim
+    assert torch.equal(view.get_root_velocities()[mask], first[mask, 7:13])
+    mdp.reset_root_state_uniform(env, mask, **rng)                                                # mask form, new numbers
+    second = d.root_state_w.clone()
+    assert torch.equal(second[~mask], before[~mask]) and (second[mask, 0] != first[mask, 0]).float().mean() > 0.99
+    # joints: by offset, clamped to the soft limits; every env (env_ids=None)
+    mdp.reset_joints_by_offset(env, None, position_range=(-0.2, 0.2), velocity_range=(-0.1, 0.1))
+    off = d.joint_pos - d.default_joint_pos
+    assert off.min() >= -0.2 - 1e-6 and off.max() <= 0.2 + 1e-6 and off.std() > 0.08
+    assert torch.equal(d._previous_joint_vel, d.joint_vel) and (d.joint_acc == 0).all()
+    assert torch.equal(view.get_dof_positions(), d.joint_pos)
+    # interval timers: global timer fires for all envs at once
+    from isaaclab_amd.managers import EventManager, EventTermCfg
+
+    calls = []
+    cfg = {"tick": EventTermCfg(func=lambda env, env_ids: calls.append(env_ids.clone()), mode="interval",
+                                interval_range_s=(0.05, 0.05), is_global_time=True)}
+    em = EventManager(cfg, env)
+    for _ in range(5):
+        em.apply("interval", dt=0.02)
+    fired = [int(c.sum().item()) for c in calls]
+    assert fired == [0, 0, n, 0, 0], fired
