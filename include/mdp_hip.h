@@ -717,6 +717,24 @@ int mdp_post_physics_step_with_reset(int num_envs, const mdp_scene_update_t* upd
 int mdp_raycaster_update_flagged(int num_envs, const mdp_raycaster_update_args_t* cast, const uint8_t* reset_mask,
                                  void* stream);
 
+/* The actuator step the reference runs right after a reset -- `self.scene.write_data_to_sim()` inside
+ * `if len(reset_env_ids) > 0:` (manager_based_rl_env.py:214-222): one more actuator evaluation for EVERY env (it advances
+ * the LSTM state of all of them) in the steps where at least one env was reset.  The condition lives on the device
+ * here: the launch does nothing unless *gate > 0 (`gate` = device float, e.g. the number of reset envs the step's
+ * statistics hold).  Otherwise identical to mdp_actuator_lstm_compute / mdp_actuator_pd_compute. */
+int mdp_actuator_lstm_compute_gated(const float* gate, const mdp_net_desc_t* desc, const float* packed_weights,
+                                    int num_envs, int num_joints, const float* q_des, int ld_q_des,
+                                    const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                    float* hidden_state, float* cell_state, const float* effort_limit,
+                                    const float* velocity_limit, float saturation_effort, float* computed_effort,
+                                    float* applied_effort, void* stream);
+int mdp_actuator_pd_compute_gated(const float* gate, int kind, int num_envs, int num_joints, const float* q_des,
+                                  int ld_q_des, const float* qd_des, int ld_qd_des, const float* tau_ff, int ld_tau_ff,
+                                  const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                  const float* stiffness, const float* damping, const float* effort_limit,
+                                  const float* velocity_limit, float saturation_effort, float* computed_effort,
+                                  float* applied_effort, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Event terms of the "reset" and "interval" modes.  The reference calls them with an id list taken
  * from nonzero() on the host (manager_based_rl_env.py:214, event_manager.py:218); here the selection is `env_mask`

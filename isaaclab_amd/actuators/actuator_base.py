@@ -118,6 +118,10 @@ class ActuatorBase(ABC):
     #: (``mdp_actuator_*_compute_with_action``); ``Articulation`` sets ``pending_joint_action`` right before ``compute``
     folds_joint_action: bool = False
     pending_joint_action = None
+    #: device float the next ``compute`` is conditional on (``mdp_actuator_*_compute_gated``: the launch does nothing
+    #: unless it is > 0); ``None`` for actuators that cannot take one.  Set by ``Articulation`` right before ``compute``
+    supports_gate: bool = False
+    pending_gate = None
 
     def _take_joint_action(self, q_des_ptr, ld_q_des):
         """The pending joint action if this launch can process it (its processed buffer IS the position target the
@@ -155,6 +159,14 @@ class ActuatorBase(ABC):
             if not p.is_contiguous():
                 setattr(self, name, p.contiguous())
         # a pending scene update (scene.update of the frame being read) rides along in the same launch
+        gate, self.pending_gate = self.pending_gate, None
+        if gate is not None:
+            L.check(L.lib.mdp_actuator_pd_compute_gated(
+                gate.data_ptr(), L.ACT_KINDS[kind], self._num_envs, self.num_joints, *args, q.data_ptr(), ld_q,
+                qd.data_ptr(), ld_qd, self.stiffness.data_ptr(), self.damping.data_ptr(), self.effort_limit.data_ptr(),
+                self.velocity_limit.data_ptr(), float(saturation), self.computed_effort.data_ptr(),
+                self.applied_effort.data_ptr(), L.stream(q.device)))
+            return
         act = self._take_joint_action(args[0], args[1])
         if act is not None:
             L.check(L.lib.mdp_actuator_pd_compute_with_action(

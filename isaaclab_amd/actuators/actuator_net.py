@@ -118,6 +118,18 @@ class ActuatorNetLSTM(DCMotor):
         q, ld_q = L.rows(joint_pos, "joint_pos")
         qd, ld_qd = L.rows(joint_vel, "joint_vel")
         des, ld_des = L.rows(control_action.joint_positions, "joint_positions")
+        gate, self.pending_gate = self.pending_gate, None
+        if gate is not None:
+            L.check(L.lib.mdp_actuator_lstm_compute_gated(
+                gate.data_ptr(), C.byref(self._net.desc), self._net.packed.data_ptr(), self._num_envs, self.num_joints,
+                des.data_ptr(), ld_des, q.data_ptr(), ld_q, qd.data_ptr(), ld_qd, self.sea_hidden_state.data_ptr(),
+                self.sea_cell_state.data_ptr(), self.effort_limit.data_ptr(), self.velocity_limit.data_ptr(),
+                float(self._saturation_effort), self.computed_effort.data_ptr(), self.applied_effort.data_ptr(),
+                L.stream(q.device)))
+            control_action.joint_efforts = self.applied_effort
+            control_action.joint_positions = None
+            control_action.joint_velocities = None
+            return control_action
         act = self._take_joint_action(des.data_ptr(), ld_des)
         if act is not None:
             L.check(L.lib.mdp_actuator_lstm_compute_with_action(
@@ -149,6 +161,7 @@ class ActuatorNetMLP(DCMotor):
 
     carries_scene_update = False   # own kernel (history shift): the update is launched separately
     folds_joint_action = False
+    supports_gate = False
 
     def __init__(self, cfg, *args, **kwargs):
         super().__init__(cfg, *args, **kwargs)

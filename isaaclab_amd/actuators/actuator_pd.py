@@ -15,6 +15,7 @@ class ImplicitActuator(ActuatorBase):
 
     carries_scene_update = True
     folds_joint_action = True
+    supports_gate = True
 
     def reset(self, *args, **kwargs):
         pass
@@ -29,6 +30,7 @@ class IdealPDActuator(ActuatorBase):
 
     carries_scene_update = True
     folds_joint_action = True
+    supports_gate = True
 
     def reset(self, env_ids: Sequence[int]):
         pass
@@ -65,6 +67,7 @@ class DelayedPDActuator(IdealPDActuator):
     """actuator_pd.py:236-293: per-env integer command lag (three delay buffers)."""
 
     folds_joint_action = False   # the delay buffers read the processed targets before the PD launch
+    supports_gate = False        # ... and advance with every compute
 
     def __init__(self, cfg, *args, **kwargs):
         super().__init__(cfg, *args, **kwargs)

@@ -183,9 +183,10 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
        const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
        const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
        const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
-       float* __restrict__ computed, float* __restrict__ applied) {
+       float* __restrict__ computed, float* __restrict__ applied, const float* __restrict__ gate) {
     constexpr int TPL = H / 4;
     extern __shared__ __align__(16) float lds[];
+    if (gate != nullptr && *gate <= 0.0f) return;      // mdp_actuator_lstm_compute_gated: nothing happens this launch
     // the carried scene update takes the FIRST blocks of the grid: its chain of dependent loads starts with the launch
     // instead of behind the actuator blocks
     const unsigned nb_upd = gridDim.x - nb_act;
@@ -309,8 +310,9 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
             const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
             const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
             const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
-            float* __restrict__ computed, float* __restrict__ applied) {
+            float* __restrict__ computed, float* __restrict__ applied, const float* __restrict__ gate) {
     constexpr int H = 8, TPL = 2;
+    if (gate != nullptr && *gate <= 0.0f) return;      // mdp_actuator_lstm_compute_gated: nothing happens this launch
     // the carried scene update takes the FIRST blocks of the grid: its chain of dependent loads starts with the launch
     // instead of behind the actuator blocks
     const unsigned nb_upd = gridDim.x - nb_act;
@@ -600,7 +602,7 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
                                                       int ld_vel, float* hidden_state, float* cell_state,
                                                       const float* effort_limit, const float* velocity_limit,
                                                       float saturation_effort, float* computed_effort,
-                                                      float* applied_effort, void* stream) {
+                                                      float* applied_effort, void* stream, const float* gate = nullptr) {
     int rc = validate(desc);
     if (rc != MDP_OK) return rc;
     MDP_REQUIRE(desc->lstm_layers >= 1, "not an LSTM network");
@@ -644,7 +646,7 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
         hipLaunchKernelGGL(k_lstm<HH>, grid, block, lds_bytes, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint, \
                            plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,     \
                            ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,      \
-                           saturation_effort, computed_effort, applied_effort);                                    \
+                           saturation_effort, computed_effort, applied_effort, gate);                              \
     } while (0)
     // register-resident weights for the ANYdrive shape (MDP_LSTM_GENERIC=1 forces the LDS kernel: parity tests)
     static const bool force_generic = [] { const char* e = std::getenv("MDP_LSTM_GENERIC"); return e && e[0] == '1'; }();
@@ -653,12 +655,12 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
             hipLaunchKernelGGL(k_lstm8_reg<1>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
                                plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
                                joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
-                               saturation_effort, computed_effort, applied_effort);
+                               saturation_effort, computed_effort, applied_effort, gate);
         else
             hipLaunchKernelGGL(k_lstm8_reg<2>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
                                plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
                                joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
-                               saturation_effort, computed_effort, applied_effort);
+                               saturation_effort, computed_effort, applied_effort, gate);
         MDP_LAUNCH_CHECK();
         return MDP_OK;
     }
@@ -709,6 +711,18 @@ extern "C" int mdp_actuator_lstm_compute(const mdp_net_desc_t* desc, const float
                                                   ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state,
                                                   cell_state, effort_limit, velocity_limit, saturation_effort,
                                                   computed_effort, applied_effort, stream);
+}
+
+extern "C" int mdp_actuator_lstm_compute_gated(const float* gate, const mdp_net_desc_t* desc, const float* packed_weights,
+                                               int num_envs, int num_joints, const float* q_des, int ld_q_des,
+                                               const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                               float* hidden_state, float* cell_state, const float* effort_limit,
+                                               const float* velocity_limit, float saturation_effort,
+                                               float* computed_effort, float* applied_effort, void* stream) {
+    MDP_REQUIRE(gate, "null gate");
+    return lstm_launch(nullptr, nullptr, 0.0f, desc, packed_weights, num_envs, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
+                       joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit, saturation_effort,
+                       computed_effort, applied_effort, stream, gate);
 }
 
 extern "C" int mdp_actuator_lstm_reset(int layers, int hidden, int num_envs, int num_joints, float* hidden_state,

@@ -24,7 +24,9 @@ k_actuator_pd(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_roo
                               const float* __restrict__ qd, int ld_qd,
                               const float* __restrict__ kp, const float* __restrict__ kd,
                               const float* __restrict__ eff_lim, const float* __restrict__ vel_lim,
-                              float sat, float* __restrict__ computed, float* __restrict__ applied) {
+                              float sat, float* __restrict__ computed, float* __restrict__ applied,
+                              const float* __restrict__ gate) {
+    if (gate != nullptr && *gate <= 0.0f) return;   // mdp_actuator_pd_compute_gated: nothing happens this launch
     const unsigned nb_upd = gridDim.x - nb_act;   // carried scene update: the first blocks of the grid
     if (blockIdx.x < nb_upd) {
         scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
@@ -153,7 +155,8 @@ static int pd_launch(const mdp_joint_action_t* action, const mdp_scene_update_t*
                                                     const float* joint_vel, int ld_vel, const float* stiffness,
                                                     const float* damping, const float* effort_limit,
                                                     const float* velocity_limit, float saturation_effort,
-                                                    float* computed_effort, float* applied_effort, void* stream) {
+                                                    float* computed_effort, float* applied_effort, void* stream,
+                                                    const float* gate = nullptr) {
     MDP_REQUIRE(num_envs >= 0 && num_joints >= 0, "negative shape (%d,%d)", num_envs, num_joints);
     SceneUpdatePlan plan;
     if (update) {
@@ -187,7 +190,7 @@ static int pd_launch(const mdp_joint_action_t* action, const mdp_scene_update_t*
     hipLaunchKernelGGL(k_actuator_pd<K>, dim3(grid), dim3(block), 0, s, plan.d, dt, nb_act, plan.nb_root,      \
                        plan.nb_joint, plan.nb_contact, plan.carried_envs, act, total, num_joints, q_des, ld_q_des, qd_des, ld_qd_des,   \
                        tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel, stiffness, damping,             \
-                       effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort)
+                       effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort, gate)
     switch (kind) {
         case MDP_ACT_IMPLICIT:
         case MDP_ACT_IDEAL_PD: LAUNCH(MDP_ACT_IDEAL_PD); break;
@@ -236,6 +239,19 @@ extern "C" int mdp_actuator_pd_compute(int kind, int num_envs, int num_joints,
                                                 ld_qd_des, tau_ff, ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel,
                                                 stiffness, damping, effort_limit, velocity_limit, saturation_effort,
                                                 computed_effort, applied_effort, stream);
+}
+
+extern "C" int mdp_actuator_pd_compute_gated(const float* gate, int kind, int num_envs, int num_joints,
+                                             const float* q_des, int ld_q_des, const float* qd_des, int ld_qd_des,
+                                             const float* tau_ff, int ld_tau_ff, const float* joint_pos, int ld_pos,
+                                             const float* joint_vel, int ld_vel, const float* stiffness,
+                                             const float* damping, const float* effort_limit,
+                                             const float* velocity_limit, float saturation_effort,
+                                             float* computed_effort, float* applied_effort, void* stream) {
+    MDP_REQUIRE(gate, "null gate");
+    return pd_launch(nullptr, nullptr, 0.0f, kind, num_envs, num_joints, q_des, ld_q_des, qd_des, ld_qd_des, tau_ff,
+                     ld_tau_ff, joint_pos, ld_pos, joint_vel, ld_vel, stiffness, damping, effort_limit, velocity_limit,
+                     saturation_effort, computed_effort, applied_effort, stream, gate);
 }
 
 extern "C" int mdp_circular_buffer_append(float* buffer, int64_t* num_pushes, int max_len, int num_envs, int dim,

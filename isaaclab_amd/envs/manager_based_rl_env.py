@@ -187,6 +187,7 @@ class ManagerBasedRLEnv:
                 reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
                 if len(reset_env_ids) > 0:
                     self._reset_idx(reset_env_ids)
+                    self.scene.write_data_to_sim()      # manager_based_rl_env.py:221 (one more actuator evaluation)
             self.command_manager.compute(dt=self.step_dt)
             if "interval" in self.event_manager.available_modes:
                 self.event_manager.apply(mode="interval", dt=self.step_dt)      # manager_based_rl_env.py:233-235
@@ -264,6 +265,7 @@ class ManagerBasedRLEnv:
             # RayCaster.reset of the done envs + their recast (the observation's lazy evaluation in the reference)
             L.check(L.lib.mdp_raycaster_update_flagged(self.num_envs, C.byref(cast), tm._dones_buf.data_ptr(),
                                                        L.stream(self.device)))
+            self.scene.write_data_to_sim(gate=self._post_reset_log)    # log[0] = number of reset envs
             self._publish_reset_log()
         else:
             L.check(L.lib.mdp_post_physics_step(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
@@ -428,7 +430,8 @@ class ManagerBasedRLEnv:
         # statistics before anything is zeroed (reward_manager.py:115-121, command_manager.py:131-136,
         # termination_manager.py:149-150)
         m = mask.to(torch.float32)
-        cnt = m.sum().clamp_(min=1.0)
+        num_reset = m.sum()
+        cnt = num_reset.clamp(min=1.0)
         log = {}
         sums = (rm._episode_sums_block[: len(rm.active_terms)] * m).sum(dim=1) / cnt / self.max_episode_length_s
         for i, name in enumerate(rm.active_terms):
@@ -447,6 +450,9 @@ class ManagerBasedRLEnv:
         self.event_manager.reset(mask)
         for term in self._reset_cmd_terms:
             term._launch(0.0, mask)           # CommandTerm.reset: resample (+ counter) for the flagged envs
+        # manager_based_rl_env.py:221: write_data_to_sim() in the steps that reset at least one env -- the condition
+        # stays on the device (the launch is empty when num_reset == 0)
+        self.scene.write_data_to_sim(gate=num_reset)
 
     def _reset_idx(self, env_ids):
         """manager_based_rl_env.py:346-391 without events / curriculum (out of scope)."""

@@ -225,6 +225,9 @@ class VelocityStepOracle:
                 if events:      # scene.reset -> reset events -> manager resets (manager_based_rl_env.py:355-359)
                     self._apply_reset_events(ids, root, q_now, qd_now, event_uniforms)
                 self.log = self.reset_idx(ids, cmd_uniforms)
+                # scene.write_data_to_sim() of manager_based_rl_env.py:221: one more actuator evaluation of EVERY env
+                # (it advances the LSTM state) in the steps that reset at least one
+                self._actuator(q_now, qd_now)
         self.command.compute(root, self.step_dt, cmd_uniforms)
         E["command"] = self.command.cmd
         if events and events.get("push_robot") is not None:     # interval events (manager_based_rl_env.py:233-235)

@@ -286,3 +286,38 @@ def test_action_processed_inside_the_actuator_launch(device, n):
             C.byref(a), L.ACT_KINDS["MDP_ACT_IDEAL_PD"], n, J, None, 0, None, 0, q.data_ptr(), J, qd.data_ptr(), J,
             kp.data_ptr(), kd.data_ptr(), lim.data_ptr(), vlim.data_ptr(), 0.0, q.data_ptr(), q.data_ptr(),
             L.stream(device)))
+
+
+@pytest.mark.parametrize("name", ("anymal_c_rough", "anymal_d_flat"))
+def test_device_conditional_actuator_step(device, name):
+    """mdp_actuator_{lstm,pd}_compute_gated: the write_data_to_sim() the reference runs only in steps that reset an env
+    (manager_based_rl_env.py:214-222) with the condition on the device -- gate == 0 leaves every output and the LSTM
+    state untouched, gate > 0 is bit-identical to the plain call."""
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+
+    kw = dict(small_terrain=True) if "rough" in name else {}
+    env, rec = make_velocity_env(name, num_envs=48, device=str(device), steps=2, seed=51, **kw)
+    rec.feed(0)
+    env.step(rec.actions[0].to(device))
+    robot = env.scene["robot"]
+    act = next(iter(robot.actuators.values()))
+    state = [act.computed_effort, act.applied_effort]
+    if hasattr(act, "sea_hidden_state"):
+        state += [act.sea_hidden_state, act.sea_cell_state]
+    start = [t.clone() for t in state]
+    robot.write_data_to_sim(gate=torch.zeros(1, device=device))
+    torch.cuda.synchronize()
+    for t, ref in zip(state, start):
+        assert torch.equal(t, ref)
+    robot.write_data_to_sim(gate=torch.full((1,), 3.0, device=device))
+    gated = [t.clone() for t in state]
+    for t, ref in zip(state, start):
+        t.copy_(ref)
+    robot.write_data_to_sim()
+    torch.cuda.synchronize()
+    for t, ref, g in zip(state, start, gated):
+        assert torch.equal(t, g)
+    if hasattr(act, "sea_hidden_state"):
+        assert not torch.equal(act.sea_hidden_state, start[2])      # the open gate did advance the LSTM state
