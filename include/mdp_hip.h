@@ -805,6 +805,30 @@ int mdp_event_push_by_setting_velocity(int num_envs, const mdp_event_push_t* arg
 int mdp_event_interval_tick(int num_envs, float* time_left, float dt, float lo, float scale, int is_global_time,
                             const float* injected_u, uint64_t* rng_state, uint8_t* trigger_mask, void* stream);
 
+/* terrain_levels_vel (TASKS/manager_based/locomotion/velocity/mdp/curriculums.py:26-55) + TerrainImporter.
+ * update_env_origins (terrain_importer.py:307-324) for the envs of `env_mask`: the distance walked from the env origin
+ * decides whether the env moves one terrain level up or down, envs beyond the last level get a random one, and the env
+ * origin becomes terrain_origins[level, type].  terrain_levels / env_origins are updated in place; the term's return
+ * value (mean level over ALL envs) is a plain reduction the caller does.  injected_levels: the randint draws (tests). */
+typedef struct {
+    const uint8_t* env_mask;
+    const float* root_state_w;         /* (N, ld_state), columns 0..1 read */
+    int32_t ld_state;
+    int32_t max_terrain_level;         /* number of terrain rows */
+    const float* command;              /* (N,3) base_velocity command */
+    float half_tile_size;              /* terrain_generator.size[0] / 2 */
+    float max_episode_length_s;
+    int64_t* terrain_levels;           /* (N) */
+    const int64_t* terrain_types;      /* (N) */
+    const float* terrain_origins;      /* (rows, num_cols, 3) */
+    int32_t num_cols;
+    int32_t pad0;
+    float* env_origins;                /* (N,3) */
+    const int64_t* injected_levels;    /* (N) or NULL */
+    uint64_t* rng_state;               /* 1 + N words (see the event terms) */
+} mdp_curriculum_terrain_t;
+int mdp_curriculum_terrain_levels_vel(int num_envs, const mdp_curriculum_terrain_t* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,6 +184,16 @@ class MdpEventPush(C.Structure):
                 ("pad0", C.c_int32)]
 
 
+class MdpCurriculumTerrain(C.Structure):
+    """Mirror of ``mdp_curriculum_terrain_t``."""
+
+    _fields_ = [("env_mask", C.c_void_p), ("root_state_w", C.c_void_p), ("ld_state", C.c_int32),
+                ("max_terrain_level", C.c_int32), ("command", C.c_void_p), ("half_tile_size", C.c_float),
+                ("max_episode_length_s", C.c_float), ("terrain_levels", C.c_void_p), ("terrain_types", C.c_void_p),
+                ("terrain_origins", C.c_void_p), ("num_cols", C.c_int32), ("pad0", C.c_int32),
+                ("env_origins", C.c_void_p), ("injected_levels", C.c_void_p), ("rng_state", C.c_void_p)]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

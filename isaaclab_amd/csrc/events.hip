@@ -152,7 +152,47 @@ __global__ void k_interval_tick_global(int N, float* time_left, float dt, float 
     for (int e = threadIdx.x; e < N; e += blockDim.x) trigger[e] = f;
 }
 
+// curriculums.py:26-55 (terrain_levels_vel) + terrain_importer.py:307-324 (update_env_origins)
+__global__ void k_terrain_levels_vel(int N, mdp_curriculum_terrain_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || (a.env_mask && !a.env_mask[e])) return;
+    const float* r = a.root_state_w + (int64_t)e * a.ld_state;
+    float* org = a.env_origins + 3 * (int64_t)e;
+    float distance = norm2(r[0] - org[0], r[1] - org[1]);
+    bool move_up = distance > a.half_tile_size;
+    bool move_down = distance < (norm2(a.command[3 * e], a.command[3 * e + 1]) * a.max_episode_length_s) * 0.5f;
+    move_down = move_down && !move_up;
+    int64_t level = a.terrain_levels[e] + (move_up ? 1 : 0) - (move_down ? 1 : 0);
+    if (level >= a.max_terrain_level) {
+        // robots that solve the last level are sent to a random one (torch.randint_like(levels, max_level))
+        if (a.injected_levels) {
+            level = a.injected_levels[e];
+        } else {
+            uint64_t seed = a.rng_state[0], epoch = a.rng_state[1 + e];
+            a.rng_state[1 + e] = epoch + 1;
+            level = (int64_t)(rng4(seed, epoch, 0x43544c56u, (uint64_t)e).x % (uint32_t)a.max_terrain_level);
+        }
+    } else if (level < 0) {
+        level = 0;
+    }
+    a.terrain_levels[e] = level;
+    const float* o = a.terrain_origins + ((int64_t)level * a.num_cols + a.terrain_types[e]) * 3;
+    org[0] = o[0]; org[1] = o[1]; org[2] = o[2];
+}
+
 }  // namespace
+
+extern "C" int mdp_curriculum_terrain_levels_vel(int num_envs, const mdp_curriculum_terrain_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->root_state_w && a->command && a->terrain_levels && a->terrain_types && a->terrain_origins &&
+                    a->env_origins, "null pointer");
+    MDP_REQUIRE(a->ld_state >= 3 && a->max_terrain_level >= 1 && a->num_cols >= 1, "bad shape");
+    MDP_REQUIRE(a->injected_levels || a->rng_state, "need rng_state or injected_levels");
+    if (num_envs <= 0) return MDP_OK;
+    hipLaunchKernelGGL(k_terrain_levels_vel, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
 
 extern "C" int mdp_event_reset_root_state_uniform(int num_envs, const mdp_event_root_state_t* a, void* stream) {
     MDP_REQUIRE(a, "null arguments");

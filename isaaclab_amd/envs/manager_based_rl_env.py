@@ -15,8 +15,8 @@ import numpy as np
 import torch
 
 from ..assets import Articulation, SyntheticPhysicsView
-from ..managers import (ActionManager, CommandManager, EventManager, ObservationManager, RewardManager,
-                        TerminationManager)
+from ..managers import (ActionManager, CommandManager, CurriculumManager, EventManager, ObservationManager,
+                        RewardManager, TerminationManager)
 from ..scene import InteractiveScene
 from ..sensors import ContactSensor, RayCaster
 from ..terrains import SyntheticTerrain, SyntheticTerrainCfg
@@ -78,6 +78,7 @@ class ManagerBasedRLEnv:
         self.seed = getattr(cfg, "seed", None)
         self.event_uniforms: dict[str, torch.Tensor] = {}     # tests: injected random numbers per event function
         self.event_manager = EventManager(getattr(cfg, "events", None), self)
+        self.curriculum_manager = CurriculumManager(getattr(cfg, "curriculum", None), self)
         self._sim_step_counter = 0
         self.obs_buf = None
         self.reward_buf = None
@@ -117,7 +118,8 @@ class ManagerBasedRLEnv:
         # sensor-owned observation columns (height scan) come from the cast kernel, on its own stream
         split = concurrent and om.can_split_sensor_terms()
         early_cast = split and self.scene.fused_update and len(om.scan_sensors()) > 0
-        has_events = any(m in self.event_manager.available_modes for m in ("reset", "interval"))
+        has_events = (any(m in self.event_manager.available_modes for m in ("reset", "interval"))
+                      or len(self.curriculum_manager.active_terms) > 0)
         if has_events:
             # event terms write the robot state between rewards and observations: the stages run one after the other
             split = early_cast = concurrent = False
@@ -427,6 +429,9 @@ class ManagerBasedRLEnv:
             self._reset_plan = self._masked_reset_plan()
         arr, count, _ = self._reset_plan
         rm, tm, cm = self.reward_manager, self.termination_manager, self.command_manager
+        # curriculum first (manager_based_rl_env.py:353): it reads the command and the root position of the episode
+        self.curriculum_manager.sync_free = True
+        self.curriculum_manager.compute(env_ids=mask)
         # statistics before anything is zeroed (reward_manager.py:115-121, command_manager.py:131-136,
         # termination_manager.py:149-150)
         m = mask.to(torch.float32)
@@ -442,6 +447,7 @@ class ManagerBasedRLEnv:
         done_counts = (tm._term_dones_block[: len(tm.active_terms)] & mask).sum(dim=1)
         for i, name in enumerate(tm.active_terms):
             log["Episode_Termination/" + name] = done_counts[i]
+        log.update(self.curriculum_manager.reset(mask))
         self.extras["log"] = log
         L.check(L.lib.mdp_masked_fill(arr, count, mask.data_ptr(), self.num_envs, L.stream(self.device)))
         if "reset" in self.event_manager.available_modes:                      # manager_based_rl_env.py:357-359
@@ -456,12 +462,13 @@ class ManagerBasedRLEnv:
 
     def _reset_idx(self, env_ids):
         """manager_based_rl_env.py:346-391 without events / curriculum (out of scope)."""
+        self.curriculum_manager.compute(env_ids=env_ids)
         self.scene.reset(env_ids)
         if "reset" in self.event_manager.available_modes:
             self.event_manager.apply(mode="reset", env_ids=env_ids,
                                      global_env_step_count=self._sim_step_counter // self.cfg.decimation)
         self.extras["log"] = dict()
-        for manager in (self.observation_manager, self.action_manager, self.reward_manager,
+        for manager in (self.observation_manager, self.action_manager, self.reward_manager, self.curriculum_manager,
                         self.command_manager, self.event_manager, self.termination_manager):
             self.extras["log"].update(manager.reset(env_ids))
         self.episode_length_buf[env_ids] = 0

@@ -98,6 +98,7 @@ class Recording:
         self.network = None                           # actuator net module (anymal_c_rough)
         self._dev_noise: dict[str, torch.Tensor] = {}
         self._dev_cmd: torch.Tensor | None = None
+        self.curriculum: dict | None = None           # terrain curriculum: initial levels, types, tile origins, tile size
         self.events: dict | None = None               # event cfg values + initial state (default root state, push timers)
         self.event_uniforms: dict[str, torch.Tensor] = {}   # event function name / "interval" -> host (steps, N, k)
         self._dev_events: dict[str, torch.Tensor] = {}
@@ -170,6 +171,10 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
 
         cfg.events = EventCfg()
     rough = cfg.scene.height_scanner is not None
+    if events and rough:                    # ... and the terrain-level curriculum where there is a generated terrain
+        from ..tasks.velocity.velocity_env_cfg import CurriculumCfg
+
+        cfg.curriculum = CurriculumCfg()
     if terrain is None and rough:
         gen = TerrainGeneratorCfg(num_rows=2, num_cols=5) if small_terrain else TerrainGeneratorCfg()
         terrain = SyntheticTerrain(SyntheticTerrainCfg(terrain_generator=gen, max_init_terrain_level=1 if small_terrain else 5),
@@ -229,6 +234,11 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
                           reset_base=dict(ecfg.reset_base.params), reset_robot_joints=dict(ecfg.reset_robot_joints.params),
                           push_robot=dict(velocity_range=ecfg.push_robot.params["velocity_range"],
                                           interval_range_s=ecfg.push_robot.interval_range_s))
+        if rough:
+            rec.curriculum = dict(terrain_levels0=np.asarray(terrain.terrain_levels, np.int64).copy(),
+                                  terrain_types=np.asarray(terrain.terrain_types, np.int64).copy(),
+                                  terrain_origins=terrain.terrain_origins.copy(),
+                                  tile_size_x=float(terrain.cfg.terrain_generator.size[0]))
         if inject_random:
             j = robot.num_joints
             widths = {"reset_root_state_uniform": 12, "reset_joints_by_scale": 2 * j, "push_by_setting_velocity": 6}
@@ -237,6 +247,13 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
                 dev = torch.zeros((num_envs, w), dtype=torch.float32, device=device)
                 env.event_uniforms[fname] = dev
                 rec._dev_events[fname] = dev
+            if rough:
+                rows = terrain.max_terrain_level
+                rec.event_uniforms["terrain_levels_vel"] = torch.from_numpy(
+                    rng.randint(0, rows, size=(steps, num_envs)).astype(np.int64))
+                dev = torch.zeros(num_envs, dtype=torch.int64, device=device)
+                env.event_uniforms["terrain_levels_vel"] = dev
+                rec._dev_events["terrain_levels_vel"] = dev
             rec.event_uniforms["interval"] = torch.from_numpy(rng.uniform(size=(steps, num_envs)).astype(np.float32))
             dev = torch.zeros(num_envs, dtype=torch.float32, device=device)
             env.event_manager.interval_uniforms[0] = dev

@@ -1,11 +1,16 @@
-"""``terrain_levels_vel`` (``TASKS/manager_based/locomotion/velocity/mdp/curriculums.py:26-55``): reset-time
-term (off the per-step hot path); kept for API completeness of the task cfg."""
+"""``terrain_levels_vel`` (``TASKS/manager_based/locomotion/velocity/mdp/curriculums.py:26-55``) with
+``TerrainImporter.update_env_origins`` (``LAB/terrains/terrain_importer.py:307-324``) folded in: one masked launch
+(``mdp_curriculum_terrain_levels_vel``).  ``env_ids`` may be ids, ``None`` / ``slice(None)``
+(every env) or a byte / bool mask of ``num_envs`` entries (the sync-free reset path)."""
 from __future__ import annotations
 
+import ctypes as C
 from collections.abc import Sequence
 
 import torch
 
+from .... import _lib as L
+from ....envs.mdp.events import _mask_ptr, _state
 from ....managers.scene_entity_cfg import SceneEntityCfg
 
 
@@ -13,9 +18,23 @@ def terrain_levels_vel(env, env_ids: Sequence[int], asset_cfg: SceneEntityCfg = 
     asset = env.scene[asset_cfg.name]
     terrain = env.scene.terrain
     command = env.command_manager.get_command("base_velocity")
-    distance = torch.norm(asset.data.root_pos_w[env_ids, :2] - env.scene.env_origins[env_ids, :2], dim=1)
-    move_up = distance > terrain.cfg.terrain_generator.size[0] / 2
-    move_down = distance < torch.norm(command[env_ids, :2], dim=1) * env.max_episode_length_s * 0.5
-    move_down *= ~move_up
-    terrain.update_env_origins(env_ids, move_up, move_down)
-    return torch.mean(terrain.terrain_levels.float())
+    st = terrain.device_state(env.device)
+    keep: list = []
+    a = L.MdpCurriculumTerrain()
+    a.env_mask = _mask_ptr(env, env_ids, keep)
+    root = asset.data.root_state_w
+    a.root_state_w, a.ld_state = root.data_ptr(), root.stride(0)
+    a.max_terrain_level = terrain.max_terrain_level
+    if not command.is_contiguous() or command.shape[1] != 3:
+        raise ValueError("base_velocity command must be a contiguous (N, 3) tensor")
+    a.command = command.data_ptr()
+    a.half_tile_size = float(terrain.cfg.terrain_generator.size[0] / 2)
+    a.max_episode_length_s = float(env.max_episode_length_s)
+    a.terrain_levels, a.terrain_types = st["terrain_levels"].data_ptr(), st["terrain_types"].data_ptr()
+    a.terrain_origins, a.num_cols = st["terrain_origins"].data_ptr(), st["terrain_origins"].shape[1]
+    a.env_origins = env.scene.env_origins.data_ptr()
+    inj = getattr(env, "event_uniforms", {}).get("terrain_levels_vel")       # tests: the randint draws, (N,) int64
+    a.injected_levels = inj.data_ptr() if inj is not None else None
+    a.rng_state = None if inj is not None else _state(env, ("terrain_levels", asset_cfg.name), 7).data_ptr()
+    L.check(L.lib.mdp_curriculum_terrain_levels_vel(env.num_envs, C.byref(a), L.stream(env.device)))
+    return torch.mean(st["terrain_levels"].float())

@@ -7,6 +7,7 @@ import math
 from dataclasses import MISSING
 
 from ...assets import ArticulationCfg
+from ...managers import CurriculumTermCfg as CurrTerm
 from ...managers import EventTermCfg as EventTerm
 from ...managers import ObservationGroupCfg as ObsGroup
 from ...managers import ObservationTermCfg as ObsTerm
@@ -153,6 +154,13 @@ class EventCfg:
 
 
 @configclass
+class CurriculumCfg:
+    """velocity_env_cfg.py:269-272."""
+
+    terrain_levels = CurrTerm(func=mdp.terrain_levels_vel)
+
+
+@configclass
 class SimCfg:
     dt: float = 0.005
     render_interval: int = 1
@@ -167,6 +175,7 @@ class LocomotionVelocityRoughEnvCfg:
     rewards: RewardsCfg = RewardsCfg()
     terminations: TerminationsCfg = TerminationsCfg()
     events: EventCfg | None = None      # EventCfg(): reset + interval events on the step path
+    curriculum: CurriculumCfg | None = None   # CurriculumCfg(): terrain levels at reset (needs a generated terrain)
     sim: SimCfg = SimCfg()
     decimation: int = 4
     episode_length_s: float = 20.0

@@ -140,6 +140,24 @@ class SyntheticTerrain:
         self.terrain_types = (np.arange(num_envs) * g.num_cols // max(num_envs, 1)).astype(np.int64)
         self.env_origins = self.terrain_origins[self.terrain_levels, self.terrain_types].astype(np.float32)
 
+    @property
+    def max_terrain_level(self) -> int:
+        return self.terrain_origins.shape[0]                   # terrain_importer.py:333
+
+    def device_state(self, device):
+        """Device copies of what the terrain curriculum reads and writes (terrain_importer.py:307-324): levels (N) int64,
+        types (N) int64, tile origins (rows, cols, 3) fp32.  Built once; ``terrain_levels`` is the live curriculum state."""
+        import torch
+
+        st = self.__dict__.get("_device_state")
+        if st is None or st["device"] != str(device):
+            st = dict(device=str(device),
+                      terrain_levels=torch.as_tensor(np.asarray(self.terrain_levels, np.int64), device=device).clone(),
+                      terrain_types=torch.as_tensor(np.asarray(self.terrain_types, np.int64), device=device).clone(),
+                      terrain_origins=torch.as_tensor(self.terrain_origins, device=device).contiguous().clone())
+            self._device_state = st
+        return st
+
     @staticmethod
     def _hf_tile(z: np.ndarray, g) -> tuple[np.ndarray, np.ndarray, float]:
         width = int(g.size[0] / g.horizontal_scale) + 1

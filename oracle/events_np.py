@@ -74,3 +74,22 @@ def interval_tick(time_left, dt, interval_range_s, u):
         lo, sc = tuple_range(interval_range_s)
         time_left[ids] = sample(u[ids], lo, sc)
     return ids
+
+
+def terrain_levels_vel(root_state, env_origins, command, ids, terrain_levels, terrain_types, terrain_origins,
+                       tile_size_x, max_episode_length_s, random_levels):
+    """curriculums.py:26-55 + terrain_importer.py:307-324, in place on ``terrain_levels`` / ``env_origins`` -> mean
+    level over all envs.  ``random_levels``: (N,) the torch.randint_like draws for envs beyond the last level."""
+    d = root_state[ids, :2].astype(np.float32) - env_origins[ids, :2].astype(np.float32)
+    distance = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)
+    move_up = distance > F(tile_size_x / 2)
+    c = command[ids, :2].astype(np.float32)
+    cn = np.sqrt(c[:, 0] * c[:, 0] + c[:, 1] * c[:, 1]).astype(np.float32)
+    move_down = distance < (cn * F(max_episode_length_s)).astype(np.float32) * F(0.5)
+    move_down &= ~move_up
+    lv = terrain_levels[ids] + move_up.astype(np.int64) - move_down.astype(np.int64)
+    max_level = terrain_origins.shape[0]
+    lv = np.where(lv >= max_level, random_levels[ids], np.clip(lv, 0, None))
+    terrain_levels[ids] = lv
+    env_origins[ids] = terrain_origins[lv, terrain_types[ids]]
+    return np.float32(np.mean(terrain_levels.astype(np.float32), dtype=np.float32))

@@ -44,6 +44,8 @@ def build_oracle(rec, threads: int = 0) -> VelocityStepOracle:
         raise NotImplementedError(f"no oracle spec for config '{rec.name}'")
     if getattr(rec, "events", None) is not None:
         spec["events"] = rec.events
+    if getattr(rec, "curriculum", None) is not None:
+        spec["curriculum"] = rec.curriculum
     orc = VelocityStepOracle(spec)
     orc.prime(rec.field("dof_positions", 0), rec.field("dof_velocities", 0))
     return orc

@@ -62,6 +62,10 @@ class VelocityStepOracle:
             self.rc_last = np.zeros(n, np.float32)
             self.rc_outdated = np.ones(n, bool)
         self._body_state = None
+        if s.get("curriculum") is not None:
+            s["env_origins"] = np.array(s["env_origins"], np.float32, copy=True)    # the curriculum moves them
+            self.terrain_levels = np.asarray(s["curriculum"]["terrain_levels0"], np.int64).copy()
+            self.curriculum_state = None
         if s.get("events") and s["events"].get("push_robot") is not None:
             self.push_time_left = np.asarray(s["events"]["push_time_left0"], np.float32).copy()
         act = s["actuator"]
@@ -222,9 +226,18 @@ class VelocityStepOracle:
         if auto_reset:
             ids = np.nonzero(self.terminated | self.time_outs)[0]
             if ids.size:
+                if s.get("curriculum") is not None:     # curriculum_manager.compute(env_ids), manager_based_rl_env.py:353
+                    from . import events_np as EV
+
+                    c = s["curriculum"]
+                    self.curriculum_state = EV.terrain_levels_vel(
+                        root, s["env_origins"], self.command.cmd, ids, self.terrain_levels, c["terrain_types"],
+                        c["terrain_origins"], c["tile_size_x"], s["episode_length_s"], event_uniforms["terrain_levels_vel"])
                 if events:      # scene.reset -> reset events -> manager resets (manager_based_rl_env.py:355-359)
                     self._apply_reset_events(ids, root, q_now, qd_now, event_uniforms)
                 self.log = self.reset_idx(ids, cmd_uniforms)
+                if s.get("curriculum") is not None:
+                    self.log["Curriculum/terrain_levels"] = self.curriculum_state      # curriculum_manager.py:88-117
                 # scene.write_data_to_sim() of manager_based_rl_env.py:221: one more actuator evaluation of EVERY env
                 # (it advances the LSTM state) in the steps that reset at least one
                 self._actuator(q_now, qd_now)

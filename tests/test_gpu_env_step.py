@@ -292,14 +292,34 @@ def test_reset_and_interval_events(device, name, mode):
     orc = build_oracle(rec)
     orc.episode_length[:] = start.numpy()
     robot = env.scene["robot"]
+    rough = "rough" in name
+    if rough:
+        # terrain curriculum (velocity_env_cfg.py:269-272): a third of the envs start on another terrain level than the
+        # one their recorded positions belong to -- they have "walked" a tile length and move up (or, beyond the last
+        # level, to a random one); the others move down or stay
+        st = env.scene.terrain.device_state(device)
+        sel = torch.arange(0, n, 3, device=device)
+        rows = st["terrain_origins"].shape[0]
+        st["terrain_levels"][sel] = (st["terrain_levels"][sel] + 1) % rows
+        env.scene.env_origins[sel] = st["terrain_origins"][st["terrain_levels"][sel], st["terrain_types"][sel]]
+        orc.terrain_levels[:] = to_np(st["terrain_levels"])
+        orc.s["env_origins"][:] = to_np(env.scene.env_origins)
+        levels0 = orc.terrain_levels.copy()
     pushed = 0
     for t in range(steps):
         rec.feed(t)
+        env.extras.pop("log", None)
         obs, rew, term, trunc, extras = env.step(rec.actions[t].to(device))
         timers_before = orc.push_time_left.copy()
         exp = oracle_step(orc, rec, t, auto_reset=True)
         pushed += int((timers_before - np.float32(env.step_dt) < 1e-6).sum())
         compare([(to_np(obs["policy"]), to_np(rew), to_np(term), to_np(trunc))], [exp])
+        if orc.log is not None:
+            for key, val in orc.log.items():
+                np.testing.assert_allclose(float(extras["log"][key]), val, rtol=1e-4, atol=1e-6, err_msg=f"{key} step {t}")
+        if rough:
+            assert_close(to_np(st["terrain_levels"]), orc.terrain_levels, msg=f"terrain levels step {t}")
+            assert_close(to_np(env.scene.env_origins), orc.s["env_origins"], msg=f"env origins step {t}")
         # the data buffers the events wrote (what the next step's actuator and terms read)
         assert_close(to_np(robot.data.joint_pos), orc._last_q, rtol=1e-6, atol=1e-6, msg=f"joint_pos step {t}")
         assert_close(to_np(robot.data.joint_vel), orc._last_qd, rtol=1e-6, atol=1e-6, msg=f"joint_vel step {t}")
@@ -308,6 +328,9 @@ def test_reset_and_interval_events(device, name, mode):
     assert pushed >= n // 2                                 # the interval timers did fire
     last = rec.field("dof_positions", steps * rec.decimation)
     assert np.abs(orc._last_q - last).max() > 0.05           # ... and the last step's resets left their joint state
+    if rough:
+        moved = orc.terrain_levels - levels0
+        assert (moved > 0).any() and (moved < 0).any()        # the curriculum moved envs both ways
 
 
 def test_event_terms_with_device_generator(device):

@@ -85,3 +85,33 @@ def test_interval_timers():
     assert fired.tolist() == [1, 2]                              # 0.019 - 0.02 < 1e-6 and 0.02 - 0.02 < 1e-6
     np.testing.assert_allclose(tl, [0.03, 12.5, 15.0, 0.98], rtol=1e-6)
     assert EV.interval_tick(tl, 0.02, (10.0, 15.0), u).size == 0
+
+
+def test_terrain_levels_vel_matches_torch_expression():
+    """curriculums.py:26-55 + terrain_importer.py:307-324 evaluated with torch on the same inputs."""
+    rng = np.random.RandomState(2)
+    n, rows, cols = 60, 4, 5
+    origins = rng.normal(scale=8.0, size=(rows, cols, 3)).astype(np.float32)
+    levels = rng.randint(0, rows, size=n).astype(np.int64)
+    types = rng.randint(0, cols, size=n).astype(np.int64)
+    env_origins = origins[levels, types].copy()
+    root = np.zeros((n, 13), np.float32)
+    root[:, :2] = env_origins[:, :2] + rng.uniform(-7, 7, size=(n, 2)).astype(np.float32)
+    cmd = rng.uniform(-0.6, 0.6, size=(n, 3)).astype(np.float32)
+    rand = rng.randint(0, rows, size=n).astype(np.int64)
+    ids = np.arange(0, n, 2)
+    lv, eo = levels.copy(), env_origins.copy()
+    mean = EV.terrain_levels_vel(root, eo, cmd, ids, lv, types, origins, 8.0, 20.0, rand)
+    t_ids = torch.from_numpy(ids)
+    t_lv, t_eo = torch.from_numpy(levels.copy()), torch.from_numpy(env_origins.copy())
+    distance = torch.norm(torch.from_numpy(root)[t_ids, :2] - t_eo[t_ids, :2], dim=1)
+    move_up = distance > 8.0 / 2
+    move_down = distance < torch.norm(torch.from_numpy(cmd)[t_ids, :2], dim=1) * 20.0 * 0.5
+    move_down *= ~move_up
+    t_lv[t_ids] += 1 * move_up - 1 * move_down
+    t_lv[t_ids] = torch.where(t_lv[t_ids] >= rows, torch.from_numpy(rand)[t_ids], torch.clip(t_lv[t_ids], 0))
+    t_eo[t_ids] = torch.from_numpy(origins)[t_lv[t_ids], torch.from_numpy(types)[t_ids]]
+    np.testing.assert_array_equal(lv, t_lv.numpy())
+    np.testing.assert_array_equal(eo, t_eo.numpy())
+    np.testing.assert_allclose(mean, torch.mean(t_lv.float()).item(), rtol=1e-6)
+    assert (lv != levels).any() and ((lv - levels) > 0).any() and ((lv - levels) < 0).any()
