@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--fuse-cast", action="store_true", help="cast the height scan inside the observation kernel")
     p.add_argument("--auto-reset", choices=("off", "masked"), default="off",
                    help="masked: every step also resets its done envs without a host sync (not the headline metric)")
+    p.add_argument("--events", action="store_true",
+                   help="with --auto-reset masked: the task's reset / interval event terms and terrain curriculum too")
     return p.parse_args()
 
 
@@ -143,7 +145,7 @@ def main():
     torch.manual_seed(1234 + rank)
     ring = args.ring
     env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
-                                 small_terrain=args.small_terrain, inject_random=False)
+                                 small_terrain=args.small_terrain, inject_random=False, events=args.events)
     env.observation_manager.persistent_output = True
     if args.auto_reset == "masked":
         env.auto_reset = "masked"
@@ -248,7 +250,7 @@ def main():
                                    f" 187-ray height scan on a {env.mesh.num_tris if hasattr(env, 'mesh') else 0}-triangle terrain,"
                                    f" ring of {ring * env.cfg.decimation} synthetic state frames",
                        "envs_per_gpu": args.envs, "hip_graph": graph is not None,
-                       "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset,
+                       "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset, "events": bool(args.events),
                        "reset_envs_last_step": resets},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -681,6 +681,16 @@ int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float 
                           const mdp_velocity_command_args_t* command, const mdp_obs_args_t* observation,
                           const mdp_raycaster_update_args_t* cast, void* stream);
 
+/* The statistics the managers' reset(env_ids) return for extras["log"] (reward_manager.py:115-121,
+ * command_manager.py:131-136, termination_manager.py:149-150) for the envs flagged in `dones`, in one launch and
+ * without an id list: log[0] = number of flagged envs, log[1..Tr] = mean(episode sum) / max_episode_length_s per
+ * reward term (episode_sums is (Tr, N), term-major), then the means of two per-env command metrics (either may be
+ * NULL -> 0), then one count per termination term (term_dones is (Tt, N)).  All 0 when no env is flagged.  Same
+ * layout as mdp_post_reset_args_t.log. */
+int mdp_reset_log(int num_envs, const uint8_t* dones, const float* episode_sums, int num_reward_terms,
+                  const float* metric_a, const float* metric_b, const uint8_t* term_dones, int num_termination_terms,
+                  float max_episode_length_s, float* log, void* stream);
+
 /* The same launch with the reset branch of the step in it (manager_based_rl_env.py:214-229, 346-391 without events and
  * curriculum): between its rewards and its command update a manager block resets the envs whose `dones` flag the
  * launch has just written -- the buffers of `fills` (DEVICE array of mdp_fill_t records, as for mdp_masked_fill) and

@@ -79,28 +79,34 @@ __global__ void k_reset_root_state_uniform(int N, mdp_event_root_state_t a) {
     zero_body_acc(a.body_acc_w, a.num_bodies, e);
 }
 
-// events.py:802-866 + articulation.py:472-508
+// events.py:802-866 + articulation.py:472-508, one thread per (env, joint).  The env's epoch word advances in the
+// thread of joint 0; every thread of the env reads it first (the threads of one env sit in one block, barrier below).
 __global__ void k_reset_joints(int N, mdp_event_joints_t a) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N || (a.env_mask && !a.env_mask[e])) return;
     const int J = a.num_joints;
-    Uniforms u = uniforms_for(a.injected_u, 2 * J, a.rng_state, 0x454a4e54u, e);
-    for (int j = 0; j < J; ++j) {
-        const int64_t i = (int64_t)e * J + j;
-        float sp = u(j) * a.pos_scale + a.pos_lo;
-        float sv = u(J + j) * a.vel_scale + a.vel_lo;
-        float q = a.mode == 0 ? a.default_joint_pos[i] * sp : a.default_joint_pos[i] + sp;
-        float qd = a.mode == 0 ? a.default_joint_vel[i] * sv : a.default_joint_vel[i] + sv;
-        q = tclamp(q, a.soft_joint_pos_limits[2 * i], a.soft_joint_pos_limits[2 * i + 1]);
-        float vl = a.soft_joint_vel_limits[i];
-        qd = tclamp(qd, -vl, vl);
-        a.joint_pos[i] = q;
-        a.joint_vel[i] = qd;
-        a.prev_joint_vel[i] = qd;
-        a.joint_acc[i] = 0.0f;
-        a.sim_dof_positions[(int64_t)e * a.ld_sim + j] = q;
-        a.sim_dof_velocities[(int64_t)e * a.ld_sim + j] = qd;
-    }
+    const int epb = blockDim.x / J;                               // whole envs per block
+    const int le = threadIdx.x / J, j = threadIdx.x - le * J;
+    const int e = blockIdx.x * epb + le;
+    const bool on = le < epb && e < N && (!a.env_mask || a.env_mask[e]);
+    uint64_t seed = 0, epoch = 0;
+    if (on && !a.injected_u) { seed = a.rng_state[0]; epoch = a.rng_state[1 + e]; }
+    __syncthreads();
+    if (!on) return;
+    if (!a.injected_u && j == 0) a.rng_state[1 + e] = epoch + 1;
+    Uniforms u{a.injected_u, 2 * J, seed, epoch, 0x454a4e54u, e};
+    const int64_t i = (int64_t)e * J + j;
+    float sp = u(j) * a.pos_scale + a.pos_lo;
+    float sv = u(J + j) * a.vel_scale + a.vel_lo;
+    float q = a.mode == 0 ? a.default_joint_pos[i] * sp : a.default_joint_pos[i] + sp;
+    float qd = a.mode == 0 ? a.default_joint_vel[i] * sv : a.default_joint_vel[i] + sv;
+    q = tclamp(q, a.soft_joint_pos_limits[2 * i], a.soft_joint_pos_limits[2 * i + 1]);
+    float vl = a.soft_joint_vel_limits[i];
+    qd = tclamp(qd, -vl, vl);
+    a.joint_pos[i] = q;
+    a.joint_vel[i] = qd;
+    a.prev_joint_vel[i] = qd;
+    a.joint_acc[i] = 0.0f;
+    a.sim_dof_positions[(int64_t)e * a.ld_sim + j] = q;
+    a.sim_dof_velocities[(int64_t)e * a.ld_sim + j] = qd;
 }
 
 // events.py:610-635 + articulation.py:400-420
@@ -216,7 +222,8 @@ extern "C" int mdp_event_reset_joints(int num_envs, const mdp_event_joints_t* a,
     MDP_REQUIRE(a->ld_sim >= a->num_joints, "ld_sim < num_joints");
     MDP_REQUIRE(a->injected_u || a->rng_state, "need rng_state or injected_u");
     if (num_envs <= 0) return MDP_OK;
-    hipLaunchKernelGGL(k_reset_joints, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    const int epb = 256 / a->num_joints;                          // num_joints <= 128: at least two envs per block
+    hipLaunchKernelGGL(k_reset_joints, dim3((unsigned)((num_envs + epb - 1) / epb)), dim3(256), 0, as_stream(stream), num_envs, *a);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

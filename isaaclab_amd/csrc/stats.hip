@@ -65,19 +65,60 @@ __global__ void k_masked_sums(const float* __restrict__ v, int rows, int N, cons
 
 struct FillTable { mdp_fill_t f[MDP_MAX_FILLS]; };
 
-// one blockIdx.y per buffer; x covers (env, element) pairs, elements fastest for (N, count) buffers
-__global__ void k_masked_fill(FillTable t, const uint8_t* __restrict__ mask, int N) {
-    const mdp_fill_t f = t.f[blockIdx.y];
-    const int64_t total = (int64_t)N * f.count;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t e, k;
-        if (f.env_stride == 1) { k = i / N; e = i - k * N; }       // term-major: envs fastest
-        else { e = i / f.count; k = i - e * f.count; }
-        if (!mask[e]) continue;
-        const int64_t at = e * f.env_stride + k * f.elem_stride;
-        if (f.elem_bytes == 4) reinterpret_cast<uint32_t*>(f.ptr)[at] = (uint32_t)f.value_bits;
-        else if (f.elem_bytes == 8) reinterpret_cast<uint64_t*>(f.ptr)[at] = f.value_bits;
-        else reinterpret_cast<uint8_t*>(f.ptr)[at] = (uint8_t)f.value_bits;
+// one wave per env: a wave whose env is not flagged leaves after one byte; a flagged one walks the buffers with its
+// lanes over the elements (few envs are flagged in a step, so the launch is mostly the mask read)
+__global__ void k_masked_fill(FillTable t, int num_fills, const uint8_t* __restrict__ mask, int N) {
+    const int e = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (e >= N || !mask[e]) return;
+    for (int fi = 0; fi < num_fills; ++fi) {
+        const mdp_fill_t& f = t.f[fi];
+        const int64_t base = (int64_t)e * f.env_stride;
+        for (int k = lane; k < f.count; k += 64) {
+            const int64_t at = base + (int64_t)k * f.elem_stride;
+            if (f.elem_bytes == 4) reinterpret_cast<uint32_t*>(f.ptr)[at] = (uint32_t)f.value_bits;
+            else if (f.elem_bytes == 8) reinterpret_cast<uint64_t*>(f.ptr)[at] = f.value_bits;
+            else reinterpret_cast<uint8_t*>(f.ptr)[at] = (uint8_t)f.value_bits;
+        }
+    }
+}
+
+// The values the managers' reset() log for the envs of `dones` (reward_manager.py:115-121, command_manager.py:131-136,
+// termination_manager.py:149-150), one block per row: row 0 = number of reset envs, rows 1..Tr = mean episode sum /
+// max_episode_length_s, then the means of the two command metrics, then one count per termination term.
+__global__ void k_reset_log(int N, const uint8_t* __restrict__ dones, const float* __restrict__ sums, int Tr,
+                            const float* __restrict__ metric_a, const float* __restrict__ metric_b,
+                            const uint8_t* __restrict__ term_dones, int Tt, float max_episode_length_s,
+                            float* __restrict__ log) {
+    const int r = blockIdx.x;
+    __shared__ double rs[256];
+    __shared__ double rc[256];
+    double s = 0.0, c = 0.0;
+    for (int e = threadIdx.x; e < N; e += blockDim.x) {
+        if (!dones[e]) continue;
+        c += 1.0;
+        if (r == 0) s += 1.0;
+        else if (r <= Tr) s += (double)sums[(int64_t)(r - 1) * N + e];
+        else if (r == Tr + 1) s += metric_a ? (double)metric_a[e] : 0.0;
+        else if (r == Tr + 2) s += metric_b ? (double)metric_b[e] : 0.0;
+        else s += term_dones[(int64_t)(r - Tr - 3) * N + e] ? 1.0 : 0.0;
+    }
+    rs[threadIdx.x] = s;
+    rc[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rc[threadIdx.x] += rc[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double sum = rs[0], cnt = rc[0];
+        float v;
+        if (r == 0 || r > Tr + 2) v = (float)sum;
+        else {
+            v = cnt > 0.0 ? (float)(sum / cnt) : 0.0f;
+            if (r <= Tr) v = v / max_episode_length_s;
+        }
+        log[r] = v;
     }
 }
 
@@ -99,8 +140,23 @@ extern "C" int mdp_masked_fill(const mdp_fill_t* fills, int num_fills, const uin
         largest = std::max<int64_t>(largest, (int64_t)num_envs * f.count);
     }
     if (largest == 0) return MDP_OK;
-    unsigned gx = (unsigned)std::min<int64_t>((largest + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_masked_fill, dim3(gx, (unsigned)num_fills), dim3(256), 0, as_stream(stream), t, env_mask, num_envs);
+    hipLaunchKernelGGL(k_masked_fill, dim3((unsigned)((num_envs + 3) / 4)), dim3(256), 0, as_stream(stream), t, num_fills,
+                       env_mask, num_envs);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_reset_log(int num_envs, const uint8_t* dones, const float* episode_sums, int num_reward_terms,
+                             const float* metric_a, const float* metric_b, const uint8_t* term_dones,
+                             int num_termination_terms, float max_episode_length_s, float* log, void* stream) {
+    MDP_REQUIRE(dones && log, "null pointer");
+    MDP_REQUIRE(num_reward_terms >= 0 && num_termination_terms >= 0, "negative term count");
+    MDP_REQUIRE(num_reward_terms == 0 || episode_sums, "null episode_sums");
+    MDP_REQUIRE(num_termination_terms == 0 || term_dones, "null term_dones");
+    MDP_REQUIRE(max_episode_length_s > 0.0f, "max_episode_length_s must be positive");
+    const int rows = 1 + num_reward_terms + 2 + num_termination_terms;
+    hipLaunchKernelGGL(k_reset_log, dim3(rows), dim3(256), 0, as_stream(stream), num_envs, dones, episode_sums,
+                       num_reward_terms, metric_a, metric_b, term_dones, num_termination_terms, max_episode_length_s, log);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -434,19 +434,34 @@ class ManagerBasedRLEnv:
         self.curriculum_manager.compute(env_ids=mask)
         # statistics before anything is zeroed (reward_manager.py:115-121, command_manager.py:131-136,
         # termination_manager.py:149-150)
-        m = mask.to(torch.float32)
-        num_reset = m.sum()
-        cnt = num_reset.clamp(min=1.0)
-        log = {}
-        sums = (rm._episode_sums_block[: len(rm.active_terms)] * m).sum(dim=1) / cnt / self.max_episode_length_s
-        for i, name in enumerate(rm.active_terms):
-            log["Episode_Reward/" + name] = sums[i]
-        for term_name, term in cm._terms.items():
-            for k, v in term.metrics.items():
-                log[f"Metrics/{term_name}/{k}"] = (v * m).sum() / cnt
-        done_counts = (tm._term_dones_block[: len(tm.active_terms)] & mask).sum(dim=1)
-        for i, name in enumerate(tm.active_terms):
-            log["Episode_Termination/" + name] = done_counts[i]
+        terms = list(cm._terms.values())
+        if len(terms) == 1 and set(terms[0].metrics) == {"error_vel_xy", "error_vel_yaw"}:
+            # one launch: count, reward means, command metric means, termination counts (layout of the fused launch's log)
+            if getattr(self, "_post_reset_log", None) is None:
+                rows = 1 + len(rm.active_terms) + 2 + len(tm.active_terms)
+                self._post_reset_log = torch.zeros(rows, dtype=torch.float32, device=self.device)
+            L.check(L.lib.mdp_reset_log(
+                self.num_envs, mask.data_ptr(), rm._episode_sums_block.data_ptr(), len(rm.active_terms),
+                terms[0].metrics["error_vel_xy"].data_ptr(), terms[0].metrics["error_vel_yaw"].data_ptr(),
+                tm._term_dones_block.data_ptr(), len(tm.active_terms), float(self.max_episode_length_s),
+                self._post_reset_log.data_ptr(), L.stream(self.device)))
+            self._publish_reset_log()
+            log = self.extras["log"]
+            num_reset = self._post_reset_log
+        else:
+            m = mask.to(torch.float32)
+            num_reset = m.sum()
+            cnt = num_reset.clamp(min=1.0)
+            log = {}
+            sums = (rm._episode_sums_block[: len(rm.active_terms)] * m).sum(dim=1) / cnt / self.max_episode_length_s
+            for i, name in enumerate(rm.active_terms):
+                log["Episode_Reward/" + name] = sums[i]
+            for term_name, term in cm._terms.items():
+                for k, v in term.metrics.items():
+                    log[f"Metrics/{term_name}/{k}"] = (v * m).sum() / cnt
+            done_counts = (tm._term_dones_block[: len(tm.active_terms)] & mask).sum(dim=1)
+            for i, name in enumerate(tm.active_terms):
+                log["Episode_Termination/" + name] = done_counts[i]
         log.update(self.curriculum_manager.reset(mask))
         self.extras["log"] = log
         L.check(L.lib.mdp_masked_fill(arr, count, mask.data_ptr(), self.num_envs, L.stream(self.device)))
