@@ -92,3 +92,57 @@ def test_full_size_slice_vs_oracle_and_properties(device, name, n, fast):
     hs._is_outdated.fill_(True)
     np.testing.assert_array_equal(to_np(hs.data.ray_hits_w), first)        # idempotent re-cast
     assert np.isfinite(outs[-1][0]).all() and np.abs(outs[-1][0][:, -187:]).max() <= 1.0   # height scan clipped to [-1, 1]
+
+
+def test_full_size_resets_inside_the_post_physics_launch(device):
+    """mdp_post_physics_step_with_reset at the benchmark size (Anymal-C rough, 4096 envs = 171 manager blocks): envs start
+    next to their time limit, so hundreds reset per step, in almost every block.  (a) an oracle slice on the same frames,
+    (b) the statistics the launch publishes (per-block slots added by the last block) against the separate-launch path
+    (mdp_reset_log) of a second env fed the same inputs, and against counts recomputed from the step's own outputs."""
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+    from oracle.harness import replay_oracle
+
+    n, steps = 4096, 4
+    envs = []
+    for single in (True, False):
+        env, rec = make_velocity_env("anymal_c_rough", num_envs=n, device=str(device), steps=steps, seed=27,
+                                     small_terrain=True, mesh_accel="grid")
+        env.observation_manager.persistent_output = True
+        env.single_launch_post_physics = single
+        env.auto_reset = "masked"
+        envs.append((env, rec))
+    g = torch.Generator().manual_seed(9)
+    start = envs[0][0].max_episode_length - torch.randint(1, steps + 8, (n,), generator=g)
+    outs, logs = [[], []], [[], []]
+    for k, (env, rec) in enumerate(envs):
+        env.episode_length_buf.copy_(start)
+        for t in range(steps):
+            rec.feed(t)
+            obs, rew, term, trunc, extras = env.step(rec.actions[t].to(device))
+            outs[k].append((to_np(obs["policy"]), to_np(rew), to_np(term), to_np(trunc)))
+            logs[k].append({key: float(v) for key, v in extras["log"].items()})
+            if t > 0:
+                done = outs[k][-1][2] | outs[k][-1][3]
+                tm = env.termination_manager
+                for i, tname in enumerate(tm.active_terms):
+                    assert logs[k][-1]["Episode_Termination/" + tname] == int((to_np(tm._term_dones_block[i]).astype(bool) & done).sum())
+    assert getattr(envs[0][0], "_single_launch_steps", 0) == steps - 1 and getattr(envs[1][0], "_single_launch_steps", 0) == 0
+    resets = sum(int((o[2] | o[3]).sum()) for o in outs[0])
+    assert resets > n // 3
+    for t in range(steps):
+        for a, b in zip(outs[0][t], outs[1][t]):
+            assert_close(a, b, rtol=1e-6, atol=1e-6, msg=f"single launch vs separate launches, step {t}")
+        assert logs[0][t].keys() == logs[1][t].keys()
+        for key in logs[0][t]:
+            np.testing.assert_allclose(logs[0][t][key], logs[1][t][key], rtol=2e-6, atol=1e-7, err_msg=f"{key} step {t}")
+    rec = envs[0][1]
+    ids = sorted(set(range(0, n, n // 96)) | set(range(n - 17, n)))
+    ref = replay_oracle(slice_recording(rec, ids), steps, auto_reset=True, episode_length0=start.numpy()[ids])
+    for t in range(steps):
+        got = [a[ids] for a in outs[0][t]]
+        np.testing.assert_array_equal(got[2], ref[t][2])
+        np.testing.assert_array_equal(got[3], ref[t][3])
+        assert_close(got[1], ref[t][1], rtol=1e-5, atol=2e-6, msg=f"reward step {t}")
+        assert_close(got[0], ref[t][0], rtol=1e-5, atol=1e-5, msg=f"obs step {t}")
