@@ -681,6 +681,27 @@ int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float 
                           const mdp_velocity_command_args_t* command, const mdp_obs_args_t* observation,
                           const mdp_raycaster_update_args_t* cast, void* stream);
 
+/* RunningStandardScaler._compute (my_code/models/my_running_standard_scaler.py:82-119), SURVEY.md 8f N2: the consumer
+ * of the observation.  mdp_scaler_prepare casts the fp64 running statistics once per update (mean32 = float(mean),
+ * std32 = sqrt(float(var)), denom = std32 + epsilon); mdp_scaler_apply is one pass over (rows, dim):
+ *   forward: out = clamp((x - mean32) / denom, -clip, clip)      inverse: out = std32 * clamp(x, -clip, clip) + mean32
+ * `out` has its own row stride, so the result can land directly in a slot of the RL library's (T, N, O) rollout
+ * storage (or in place, out == x).  The statistics themselves come from mdp_stats_moments (+ the cross-rank merge). */
+/* Training-mode update (my_running_standard_scaler.py:57-80, 94-105) in two launches: mdp_stats_moments_chunked writes
+ * `num_chunks` Chan-mergeable partial rows [n, sum x (dim), M2 (dim)] of the (rows, dim) batch (coalesced reads, fp64
+ * accumulation); mdp_scaler_update merges `num_partials` such rows -- this rank's, or every rank's after one all-gather
+ * -- into the batch mean and torch.var (Bessel-corrected), applies the parallel-variance update to the fp64 running
+ * statistics (current_count: one double) and refreshes the fp32 casts. */
+int mdp_stats_moments_chunked(const float* x, int64_t rows, int dim, int64_t ld, int num_chunks, double* partials,
+                              void* stream);
+int mdp_scaler_update(int num_partials, int dim, const double* partials, double* running_mean,
+                      double* running_variance, double* current_count, float epsilon, float* mean32, float* std32,
+                      float* denom, void* stream);
+int mdp_scaler_prepare(int dim, const double* running_mean, const double* running_variance, float epsilon,
+                       float* mean32, float* std32, float* denom, void* stream);
+int mdp_scaler_apply(int64_t rows, int dim, const float* x, int64_t ld, const float* mean32, const float* std32,
+                     const float* denom, float clip_threshold, int inverse, float* out, int64_t ld_out, void* stream);
+
 /* The statistics the managers' reset(env_ids) return for extras["log"] (reward_manager.py:115-121,
  * command_manager.py:131-136, termination_manager.py:149-150) for the envs flagged in `dones`, in one launch and
  * without an id list: log[0] = number of flagged envs, log[1..Tr] = mean(episode sum) / max_episode_length_s per

@@ -122,7 +122,162 @@ __global__ void k_reset_log(int N, const uint8_t* __restrict__ dones, const floa
     }
 }
 
+// Batch moments in row chunks: block (column group of 32, chunk) reads its rows coalesced (32 consecutive floats per
+// row), two passes over its own chunk (sum -> chunk mean -> centred M2, the second pass hits L2), and writes one
+// Chan-mergeable partial row [n, sum x (D), M2 (D)] per chunk.  gridDim = (ceil(D / 32), num_chunks), block (32, 8).
+__global__ void k_moments_chunks(const float* __restrict__ x, int64_t rows, int D, int64_t ld, int num_chunks,
+                                 double* __restrict__ partials) {
+    const int c = blockIdx.x * 32 + threadIdx.x;
+    const int chunk = blockIdx.y;
+    const int64_t per = (rows + num_chunks - 1) / num_chunks;
+    const int64_t r0 = chunk * per, r1 = r0 + per < rows ? r0 + per : rows;
+    const int64_t n = r1 > r0 ? r1 - r0 : 0;
+    __shared__ double red[8][33];
+    double s = 0.0;
+    if (c < D)
+        for (int64_t r = r0 + threadIdx.y; r < r1; r += 8) s += (double)x[r * ld + c];
+    red[threadIdx.y][threadIdx.x] = s;
+    __syncthreads();
+    double sum = 0.0;
+    for (int k = 0; k < 8; ++k) sum += red[k][threadIdx.x];
+    const double mean = n > 0 ? sum / (double)n : 0.0;
+    __syncthreads();
+    double m2 = 0.0;
+    if (c < D)
+        for (int64_t r = r0 + threadIdx.y; r < r1; r += 8) {
+            double d = (double)x[r * ld + c] - mean;
+            m2 += d * d;
+        }
+    red[threadIdx.y][threadIdx.x] = m2;
+    __syncthreads();
+    if (threadIdx.y == 0 && c < D) {
+        double t = 0.0;
+        for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+        double* row = partials + (int64_t)chunk * (1 + 2 * D);
+        if (c == 0) row[0] = (double)n;
+        row[1 + c] = sum;
+        row[1 + D + c] = t;
+    }
+}
+
+// RunningStandardScaler._parallel_variance (my_running_standard_scaler.py:57-80) fed by partial rows (row chunks of this
+// rank's batch, and the other ranks' chunks behind them after an all-gather): Chan merge of the rows in order -> batch
+// mean and Bessel-corrected variance (torch.var) -> running update -> the fp32 casts mdp_scaler_apply reads.
+// One block; thread per column.
+__global__ void k_scaler_update(int P, int D, const double* __restrict__ partials, double* __restrict__ running_mean,
+                                double* __restrict__ running_var, double* __restrict__ count, float eps,
+                                float* __restrict__ mean32, float* __restrict__ std32, float* __restrict__ denom) {
+    const double cur = count[0];
+    double total_n = 0.0;
+    for (int p = 0; p < P; ++p) total_n += partials[(int64_t)p * (1 + 2 * D)];
+    __syncthreads();                                   // every thread has read the count before thread 0 replaces it
+    for (int c = threadIdx.x; c < D; c += blockDim.x) {
+        double n = 0.0, mean = 0.0, m2 = 0.0;
+        for (int p = 0; p < P; ++p) {
+            const double* row = partials + (int64_t)p * (1 + 2 * D);
+            const double nb = row[0];
+            if (nb <= 0.0) continue;
+            const double mb = row[1 + c] / nb;
+            const double delta = mb - mean, tot = n + nb;
+            mean += delta * nb / tot;
+            m2 += row[1 + D + c] + delta * delta * n * nb / tot;
+            n = tot;
+        }
+        if (n > 0.0) {
+            const double var_b = m2 / (n > 1.0 ? n - 1.0 : 1.0);
+            const double delta = mean - running_mean[c];
+            const double tot = cur + n;
+            const double M2 = running_var[c] * cur + var_b * n + delta * delta * cur * n / tot;
+            running_mean[c] = running_mean[c] + delta * n / tot;
+            running_var[c] = M2 / tot;
+        }
+        const float sd = sqrtf((float)running_var[c]);
+        mean32[c] = (float)running_mean[c];
+        std32[c] = sd;
+        denom[c] = sd + eps;
+    }
+    if (threadIdx.x == 0 && total_n > 0.0) count[0] = cur + total_n;
+}
+
+// my_running_standard_scaler.py:108-119: the fp64 running statistics are cast to fp32 once per update, not per element
+__global__ void k_scaler_prepare(int D, const double* __restrict__ mean, const double* __restrict__ var, float eps,
+                                 float* __restrict__ mean32, float* __restrict__ std32, float* __restrict__ denom) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= D) return;
+    float s = sqrtf((float)var[c]);
+    mean32[c] = (float)mean[c];
+    std32[c] = s;
+    denom[c] = s + eps;
+}
+
+// clamp((x - mean) / (sqrt(var) + eps), -clip, clip) -- or the inverse map -- written wherever the caller wants it
+// (a slot of the rollout storage): one pass over (rows, D)
+template <bool INVERSE>
+__global__ void k_scaler_apply(int64_t rows, int D, const float* __restrict__ x, int64_t ld, const float* __restrict__ mean32,
+                               const float* __restrict__ std32, const float* __restrict__ denom, float clip,
+                               float* __restrict__ out, int64_t ld_out) {
+    const int64_t total = rows * D;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int c = (int)(i - r * D);
+        const float v = x[r * ld + c];
+        float y;
+        if (INVERSE) y = std32[c] * tclamp(v, -clip, clip) + mean32[c];
+        else y = tclamp((v - mean32[c]) / denom[c], -clip, clip);
+        out[r * ld_out + c] = y;
+    }
+}
+
 }  // namespace
+
+extern "C" int mdp_stats_moments_chunked(const float* x, int64_t rows, int dim, int64_t ld, int num_chunks,
+                                         double* partials, void* stream) {
+    MDP_REQUIRE(x && partials, "null pointer");
+    MDP_REQUIRE(rows >= 0 && dim > 0 && ld >= dim, "bad dim/ld");
+    MDP_REQUIRE(num_chunks >= 1 && num_chunks <= 65535, "num_chunks out of range");
+    hipLaunchKernelGGL(k_moments_chunks, dim3((unsigned)((dim + 31) / 32), (unsigned)num_chunks), dim3(32, 8), 0,
+                       as_stream(stream), x, rows, dim, ld, num_chunks, partials);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_scaler_update(int num_partials, int dim, const double* partials, double* running_mean,
+                                 double* running_variance, double* current_count, float epsilon, float* mean32,
+                                 float* std32, float* denom, void* stream) {
+    MDP_REQUIRE(partials && running_mean && running_variance && current_count && mean32 && std32 && denom, "null pointer");
+    MDP_REQUIRE(num_partials >= 0 && dim > 0, "bad shape");
+    hipLaunchKernelGGL(k_scaler_update, dim3(1), dim3(256), 0, as_stream(stream), num_partials, dim, partials,
+                       running_mean, running_variance, current_count, epsilon, mean32, std32, denom);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_scaler_prepare(int dim, const double* running_mean, const double* running_variance, float epsilon,
+                                  float* mean32, float* std32, float* denom, void* stream) {
+    MDP_REQUIRE(running_mean && running_variance && mean32 && std32 && denom, "null pointer");
+    if (dim <= 0) return MDP_OK;
+    hipLaunchKernelGGL(k_scaler_prepare, dim3(grid_for(dim, 256)), dim3(256), 0, as_stream(stream), dim, running_mean,
+                       running_variance, epsilon, mean32, std32, denom);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_scaler_apply(int64_t rows, int dim, const float* x, int64_t ld, const float* mean32, const float* std32,
+                                const float* denom, float clip_threshold, int inverse, float* out, int64_t ld_out,
+                                void* stream) {
+    MDP_REQUIRE(x && mean32 && std32 && denom && out, "null pointer");
+    MDP_REQUIRE(rows >= 0 && dim > 0 && ld >= dim && ld_out >= dim, "bad shape");
+    if (rows == 0) return MDP_OK;
+    const unsigned grid = grid_for(rows * dim, 256, 1 << 16);
+    if (inverse)
+        hipLaunchKernelGGL(k_scaler_apply<true>, dim3(grid), dim3(256), 0, as_stream(stream), rows, dim, x, ld, mean32, std32,
+                           denom, clip_threshold, out, ld_out);
+    else
+        hipLaunchKernelGGL(k_scaler_apply<false>, dim3(grid), dim3(256), 0, as_stream(stream), rows, dim, x, ld, mean32, std32,
+                           denom, clip_threshold, out, ld_out);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
 
 extern "C" int mdp_masked_fill(const mdp_fill_t* fills, int num_fills, const uint8_t* env_mask, int num_envs, void* stream) {
     MDP_REQUIRE(num_fills >= 0 && num_fills <= MDP_MAX_FILLS, "at most %d buffers per call (got %d)", MDP_MAX_FILLS, num_fills);

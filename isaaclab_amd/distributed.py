@@ -28,10 +28,11 @@ def shard_range(num_envs_total: int, rank: int, world: int) -> tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def merge_moments(partials: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+def merge_moments(partials: torch.Tensor, unbiased: bool = True) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Chan merge of per-rank ``[n, sum x (D), M2 (D)]`` rows (G, 1 + 2D) fp64 -> (count, mean (D), var (D)).
 
-    ``var`` is the population variance of the union, like ``my_running_standard_scaler.py:69-80``."""
+    ``var`` is the variance of the union the scaler feeds to its running update: ``torch.var`` of the batch
+    (``my_running_standard_scaler.py:94-105``), i.e. with Bessel's correction (``unbiased=False``: population)."""
     p = partials.to(torch.float64)
     d = (p.shape[1] - 1) // 2
     n = p[:, 0]
@@ -39,7 +40,7 @@ def merge_moments(partials: torch.Tensor) -> tuple[torch.Tensor, torch.Tensor, t
     mean = p[:, 1 : 1 + d].sum(dim=0) / total
     mean_r = p[:, 1 : 1 + d] / n.clamp(min=1.0)[:, None]
     m2 = (p[:, 1 + d :] + n[:, None] * (mean_r - mean[None, :]) ** 2).sum(dim=0)
-    return total, mean, m2 / total
+    return total, mean, m2 / ((total - 1.0).clamp(min=1.0) if unbiased else total)
 
 
 def running_update(mean, var, count, batch_mean, batch_var, batch_count):

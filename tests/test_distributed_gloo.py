@@ -91,11 +91,11 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     r = [np.load(tmp_path / f"rank{k}.npz") for k in range(WORLD)]
     obs, sums, mask, succ, resets = _data()
     # single-process reference of the same running update (my_running_standard_scaler.py:57-80: count starts at 1,
-    # mean 0, var 1; batch variance is the population variance of the merged batch)
+    # mean 0, var 1; batch variance is torch.var of the merged batch, Bessel-corrected)
     mean, var, count = np.zeros(D), np.ones(D), 1.0
     for t in range(obs.shape[0]):
         x = obs[t].astype(np.float64)
-        bm, bv, bn = x.mean(0), x.var(0), float(N)
+        bm, bv, bn = x.mean(0), x.var(0, ddof=1), float(N)
         delta, tot = bm - mean, count + bn
         m2 = var * count + bv * bn + delta ** 2 * count * bn / tot
         mean, var, count = mean + delta * bn / tot, m2 / tot, tot
