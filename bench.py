@@ -53,6 +53,8 @@ def parse():
     p.add_argument("--fuse-cast", action="store_true", help="cast the height scan inside the observation kernel")
     p.add_argument("--auto-reset", choices=("off", "masked"), default="off",
                    help="masked: every step also resets its done envs without a host sync (not the headline metric)")
+    p.add_argument("--normalize-obs", action="store_true",
+                   help="also leave the standardised, clipped observation in a storage slot (not the headline metric)")
     p.add_argument("--events", action="store_true",
                    help="with --auto-reset masked: the task's reset / interval event terms and terrain curriculum too")
     return p.parse_args()
@@ -149,6 +151,11 @@ def main():
     env.observation_manager.persistent_output = True
     if args.auto_reset == "masked":
         env.auto_reset = "masked"
+    if args.normalize_obs:
+        from isaaclab_amd.rl import RunningStandardScaler
+
+        width = env.observation_manager.group_obs_dim["policy"][0]
+        env.set_obs_normalizer(RunningStandardScaler(width, device=device))
     if "height_scanner" in env.scene.sensors:
         env.scene.sensors["height_scanner"].fuse_into_observations = args.fuse_cast
     # episode_length_buf ~ U{0..999}
@@ -250,7 +257,7 @@ def main():
                                    f" 187-ray height scan on a {env.mesh.num_tris if hasattr(env, 'mesh') else 0}-triangle terrain,"
                                    f" ring of {ring * env.cfg.decimation} synthetic state frames",
                        "envs_per_gpu": args.envs, "hip_graph": graph is not None,
-                       "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset, "events": bool(args.events),
+                       "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset, "events": bool(args.events), "normalize_obs": bool(args.normalize_obs),
                        "reset_envs_last_step": resets},
             "roofline": roof, "cpu_baseline": cpu,
         }

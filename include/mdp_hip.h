@@ -328,6 +328,19 @@ typedef struct {
     float weight;
 } mdp_term_t;
 
+/* The observation's consumer folded into the kernels that produce it: next to the raw value v of
+ * observation column c the producing thread also stores clamp((v - mean32[c]) / denom[c], -clip, clip) -- the forward
+ * map of mdp_scaler_apply, bit for bit -- into out[env * ld_out + c], e.g. the current slot of the RL library's
+ * rollout storage.  mean32 / denom: the tables mdp_scaler_prepare / mdp_scaler_update maintain, one entry per
+ * observation column.  out == NULL: off. */
+typedef struct {
+    const float* mean32;
+    const float* denom;
+    float* out;
+    int32_t ld_out;
+    float clip;
+} mdp_obs_normalize_t;
+
 /* height_scan observation (LAB/envs/mdp/observations.py:165-173: sensor.pos_w.z - ray_hits_w.z - offset) and its
  * post-processing (observation_manager.py:313-318: noise -> clip -> scale, described by the post-processing fields of
  * `post`) written by the CAST kernel itself into columns [col_offset, col_offset + R) of the observation tensor: the
@@ -342,6 +355,7 @@ typedef struct mdp_height_scan_obs {
     int32_t pad0;
     uint64_t* rng;
     mdp_term_t post;
+    mdp_obs_normalize_t normalize;   /* tables indexed by the observation column (col_offset + ray) */
 } mdp_height_scan_obs_t;
 
 /* Ray-caster binding for a fused height-scan observation term (op MDP_OBS_HEIGHT_SCAN_CAST): the
@@ -657,6 +671,7 @@ typedef struct {
     float* obs;
     int32_t ld_obs;
     int32_t pad0;
+    mdp_obs_normalize_t normalize;   /* mdp_post_physics_step only (the cast member carries its own copy in `scan`) */
 } mdp_obs_args_t;
 
 typedef struct {

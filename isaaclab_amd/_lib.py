@@ -61,12 +61,19 @@ class MdpRaycasterDesc(C.Structure):
     ]
 
 
+class MdpObsNormalize(C.Structure):
+    """Mirror of ``mdp_obs_normalize_t``."""
+
+    _fields_ = [("mean32", C.c_void_p), ("denom", C.c_void_p), ("out", C.c_void_p), ("ld_out", C.c_int32),
+                ("clip", C.c_float)]
+
+
 class MdpHeightScanObs(C.Structure):
     """Mirror of ``mdp_height_scan_obs_t``."""
 
     _fields_ = [
         ("obs", C.c_void_p), ("ld_obs", C.c_int32), ("col_offset", C.c_int32), ("offset", C.c_float),
-        ("pad0", C.c_int32), ("rng", C.c_void_p), ("post", MdpTerm),
+        ("pad0", C.c_int32), ("rng", C.c_void_p), ("post", MdpTerm), ("normalize", MdpObsNormalize),
     ]
 
 
@@ -109,7 +116,8 @@ class MdpVelocityCommandArgs(C.Structure):
 class MdpObsArgs(C.Structure):
     """Mirror of ``mdp_obs_args_t``."""
 
-    _fields_ = [("program", C.c_void_p), ("obs", C.c_void_p), ("ld_obs", C.c_int32), ("pad0", C.c_int32)]
+    _fields_ = [("program", C.c_void_p), ("obs", C.c_void_p), ("ld_obs", C.c_int32), ("pad0", C.c_int32),
+                ("normalize", MdpObsNormalize)]
 
 
 class MdpRaycasterUpdateArgs(C.Structure):

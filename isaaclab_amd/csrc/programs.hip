@@ -681,6 +681,7 @@ struct PostArgs {
     mdp_velocity_command_args_t cmd;
     const mdp_term_t* oterms; int To; const int32_t* opool; const int16_t* col2term; int O;
     float* obs; int ld_obs; uint64_t* orng; unsigned orng_base; int ouses_rng;
+    mdp_obs_normalize_t onorm;
     // ---- reset branch (k_post_physics<.., true> only)
     const mdp_fill_t* fills; int num_fills; float max_episode_length_s; double* log_sums; float* log;
 };
@@ -894,6 +895,9 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
             float v = obs_value(t, a.opool, ee, k);
             v = obs_post(t, v, ee, k, seed, epoch | (1ull << 62), 0x4f425300u + (uint32_t)ti, (uint64_t)ee * (uint64_t)O + c);
             a.obs[(int64_t)ee * a.ld_obs + c] = v;
+            if (a.onorm.out)     // the standardised copy for the observation's consumer (mdp_obs_normalize_t)
+                a.onorm.out[(int64_t)ee * a.onorm.ld_out + c] =
+                    tclamp((v - a.onorm.mean32[c]) / a.onorm.denom[c], -a.onorm.clip, a.onorm.clip);
         }
         if (a.ouses_rng && threadIdx.x == 0) a.orng[a.orng_base + b] = epoch + 1;
     }
@@ -1204,6 +1208,9 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
             MDP_REQUIRE(sc->ld_obs >= sc->col_offset + cast->num_rays && sc->col_offset >= 0, "height-scan columns do not fit");
             const bool generated = (sc->post.noise_kind == 1 || sc->post.noise_kind == 2) && !sc->post.noise_u;
             MDP_REQUIRE(!generated || sc->rng, "generated noise needs the rng words");
+            MDP_REQUIRE(!sc->normalize.out || (sc->normalize.mean32 && sc->normalize.denom &&
+                                                  sc->normalize.ld_out >= sc->col_offset + cast->num_rays),
+                        "height-scan normalize: bad tables / ld_out");
             ra.scan = *sc;
             if (!generated) ra.scan.rng = nullptr;
         }
@@ -1248,6 +1255,11 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
             a.oterms = op->d_terms; a.To = op->num_terms; a.opool = op->d_pool; a.col2term = op->d_col2term;
             a.O = op->active_cols; a.obs = observation->obs; a.ld_obs = observation->ld_obs; a.orng = op->d_rng; a.orng_base = op->rng_post_base;
             a.ouses_rng = op->uses_rng;
+            if (observation->normalize.out) {
+                MDP_REQUIRE(observation->normalize.mean32 && observation->normalize.denom &&
+                                observation->normalize.ld_out >= op->total_cols, "observation normalize: bad tables / ld_out");
+                a.onorm = observation->normalize;
+            }
             lds += (size_t)op->num_terms * sizeof(mdp_term_t) + (size_t)a.O * sizeof(int16_t) + 16;
         }
     }

@@ -612,6 +612,9 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
                     scan->col_offset + num_rays, scan->ld_obs);
         const bool generated = (scan->post.noise_kind == 1 || scan->post.noise_kind == 2) && !scan->post.noise_u;
         MDP_REQUIRE(!generated || scan->rng, "generated noise needs the rng words");
+        MDP_REQUIRE(!scan->normalize.out || (scan->normalize.mean32 && scan->normalize.denom &&
+                                              scan->normalize.ld_out >= scan->col_offset + num_rays),
+                    "height-scan normalize: bad tables / ld_out");
         sc = *scan;
         if (!generated) sc.rng = nullptr;
     }
@@ -667,6 +670,9 @@ extern "C" int mdp_raycaster_update_flagged(int num_envs, const mdp_raycaster_up
         MDP_REQUIRE(sc->ld_obs >= sc->col_offset + num_rays && sc->col_offset >= 0, "height-scan columns do not fit");
         const bool generated = (sc->post.noise_kind == 1 || sc->post.noise_kind == 2) && !sc->post.noise_u;
         MDP_REQUIRE(!generated || sc->rng, "generated noise needs the rng words");
+        MDP_REQUIRE(!sc->normalize.out || (sc->normalize.mean32 && sc->normalize.denom &&
+                                              sc->normalize.ld_out >= sc->col_offset + num_rays),
+                    "height-scan normalize: bad tables / ld_out");
         ra.scan = *sc;
         if (!generated) ra.scan.rng = nullptr;
     }

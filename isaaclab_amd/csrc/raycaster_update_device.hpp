@@ -35,6 +35,11 @@ __device__ __forceinline__ void scan_store(const mdp_height_scan_obs_t& sc, int 
     float v = (sensor_z - hit_z) - sc.offset;   // observations.py:173
     v = obs_post(sc.post, v, e, r, seed, epoch, 0x48534341u, (uint64_t)e * (uint64_t)R + (uint64_t)r);
     sc.obs[(int64_t)e * sc.ld_obs + sc.col_offset + r] = v;
+    if (sc.normalize.out) {      // the standardised copy for the observation's consumer (mdp_obs_normalize_t)
+        const int c = sc.col_offset + r;
+        sc.normalize.out[(int64_t)e * sc.normalize.ld_out + c] =
+            tclamp((v - sc.normalize.mean32[c]) / sc.normalize.denom[c], -sc.normalize.clip, sc.normalize.clip);
+    }
 }
 
 // yaw-only attachment and a pattern whose directions are all (0, 0, -c), on a mesh with cell records.  A block owns

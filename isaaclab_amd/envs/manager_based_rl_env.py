@@ -79,6 +79,10 @@ class ManagerBasedRLEnv:
         self.event_uniforms: dict[str, torch.Tensor] = {}     # tests: injected random numbers per event function
         self.event_manager = EventManager(getattr(cfg, "events", None), self)
         self.curriculum_manager = CurriculumManager(getattr(cfg, "curriculum", None), self)
+        # the observation's consumer: see set_obs_normalizer
+        self.obs_normalizer = None
+        self.normalized_obs: torch.Tensor | None = None
+        self._normalized_in_kernel = False
         self._sim_step_counter = 0
         self.obs_buf = None
         self.reward_buf = None
@@ -102,6 +106,31 @@ class ManagerBasedRLEnv:
     @property
     def max_episode_length(self) -> int:
         return math.ceil(self.max_episode_length_s / self.step_dt)
+
+    def set_obs_normalizer(self, scaler, out: torch.Tensor | None = None, group: str = "policy"):
+        """Every step also leaves ``scaler(obs[group])`` -- standardised and clipped, evaluation mode -- in ``out``
+        (``(num_envs, obs_dim)`` with any row stride, e.g. the current slot of the RL library's rollout storage; a buffer
+        of the env's own when omitted), available as ``env.normalized_obs``.  On the single-launch path the kernels that
+        produce the observation write it (``mdp_obs_normalize_t``), otherwise one ``mdp_scaler_apply`` follows the
+        observation.  The running statistics are the caller's business (``scaler(x, train=True)``)."""
+        self.obs_normalizer, self._normalize_group = scaler, group
+        self.normalized_obs = out
+
+    def _normalize_args(self, width: int):
+        from .. import _lib as L
+
+        sc = self.obs_normalizer
+        if sc.size != width:
+            raise ValueError(f"obs normalizer size {sc.size} != observation width {width}")
+        if self.normalized_obs is None:
+            self.normalized_obs = torch.empty((self.num_envs, width), dtype=torch.float32, device=self.device)
+        out = self.normalized_obs
+        if out.shape != (self.num_envs, width) or out.dtype != torch.float32 or out.stride(1) != 1:
+            raise ValueError("normalized_obs must be a float32 (num_envs, obs_dim) tensor with unit column stride")
+        a = L.MdpObsNormalize()
+        a.mean32, a.denom, a.out = sc._mean32.data_ptr(), sc._denom.data_ptr(), out.data_ptr()
+        a.ld_out, a.clip = out.stride(0), float(sc.clip_threshold)
+        return a
 
     # -- stepping -----------------------------------------------------------------------------------------
     def step(self, action: torch.Tensor):
@@ -194,6 +223,12 @@ class ManagerBasedRLEnv:
             if "interval" in self.event_manager.available_modes:
                 self.event_manager.apply(mode="interval", dt=self.step_dt)      # manager_based_rl_env.py:233-235
             self.obs_buf = self.observation_manager.compute()
+        if self.obs_normalizer is not None:
+            if not self._normalized_in_kernel:
+                obs = self.obs_buf[self._normalize_group]
+                self._normalize_args(obs.shape[1])
+                self.obs_normalizer(obs, out=self.normalized_obs)
+            self._normalized_in_kernel = False
         self.reset_terminated = self.termination_manager.terminated
         self.reset_time_outs = self.termination_manager.time_outs
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
@@ -246,6 +281,13 @@ class ManagerBasedRLEnv:
         tr.reward_buf, tr.episode_sums = rm._reward_buf.data_ptr(), rm._episode_sums_block.data_ptr()
         tr.step_reward = rm._step_reward.data_ptr()
         ca = terms[0].fill_post_physics(self.step_dt)
+        if self.obs_normalizer is not None and self._normalize_group == group_name:
+            na = self._normalize_args(out.shape[1])
+            obs_args.normalize = na
+            scan.normalize = na
+            self._normalized_in_kernel = True
+        else:
+            scan.normalize.out = None
         cast = sensor.fill_post_physics(scan, self.physics_dt)
         oprog.run_before()
         if reset:

@@ -386,3 +386,39 @@ def test_event_terms_with_device_generator(device):
         em.apply("interval", dt=0.02)
     fired = [int(c.sum().item()) for c in calls]
     assert fired == [0, 0, n, 0, 0], fired
+
+
+@pytest.mark.parametrize("mode", (False, "masked"))
+def test_normalised_observation_written_by_the_producing_kernels(device, mode):
+    """mdp_obs_normalize_t: on the single-launch path the manager blocks and the cast blocks also store
+    the standardised, clipped observation into a slot of a rollout storage -- bit-identical to mdp_scaler_apply on the
+    finished observation, within 1e-5 of the oracle's restatement of RunningStandardScaler; step 0 (separate launches)
+    goes through mdp_scaler_apply.  With resets the flagged recast rewrites the columns of the envs it casts again."""
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+    from isaaclab_amd.rl import RunningStandardScaler
+    from oracle.scaler_np import RunningStandardScalerNP
+
+    n, steps = 80, 5
+    env, rec = make_velocity_env("anymal_c_rough", num_envs=n, device=str(device), steps=steps, seed=61, small_terrain=True,
+                                 mesh_accel="grid")
+    env.observation_manager.persistent_output = True
+    env.auto_reset = mode
+    if mode:
+        g = torch.Generator().manual_seed(7)
+        env.episode_length_buf.copy_(env.max_episode_length - torch.randint(1, steps + 2, (n,), generator=g))
+    sc, orc = RunningStandardScaler(235, device=device), RunningStandardScalerNP(235)
+    warm = (np.random.RandomState(1).normal(size=(300, 235)) * 0.3 + 0.1).astype(np.float32)
+    sc(torch.from_numpy(warm).to(device), train=True)
+    orc.compute(warm, train=True)
+    storage = torch.full((steps, n, 235 + 5), 7.0, device=device)
+    for t in range(steps):
+        rec.feed(t)
+        env.set_obs_normalizer(sc, out=storage[t, :, :235])
+        obs, *_ = env.step(rec.actions[t].to(device))
+        raw = obs["policy"]
+        assert torch.equal(storage[t, :, :235], sc(raw)), f"step {t}"
+        assert_close(to_np(storage[t, :, :235]), orc.compute(to_np(raw)), rtol=1e-5, atol=1e-6, msg=f"step {t}")
+    assert getattr(env, "_single_launch_steps", 0) == steps - 1
+    assert (storage[..., 235:] == 7.0).all() and float(storage[..., :235].abs().max()) <= 5.0
