@@ -893,9 +893,200 @@ def gen_inhand():
     save("inhand", **out)
 
 
+class _RandQueue:
+    """Replaces torch.rand / torch.randint_like while a reference function runs: hands out the prepared tensors in call
+    order (shape-checked), so the reference consumes exactly the numbers the fixture records."""
+
+    def __init__(self, rand=(), randint=()):
+        self.rand, self.randint = list(rand), list(randint)
+
+    def __enter__(self):
+        self._rand, self._randint_like = torch.rand, torch.randint_like
+
+        def rand(*size, **kw):
+            size = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            t = self.rand.pop(0)
+            assert tuple(t.shape) == size, (tuple(t.shape), size)
+            return t.clone()
+
+        def randint_like(x, *a, **kw):
+            t = self.randint.pop(0)
+            assert t.shape == x.shape, (t.shape, x.shape)
+            return t.clone().to(x.dtype)
+
+        torch.rand, torch.randint_like = rand, randint_like
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randint_like = self._rand, self._randint_like
+        assert not self.rand and not self.randint, "the reference drew fewer numbers than prepared"
+
+
+def gen_events():
+    """Reset / interval event terms, the terrain-level curriculum and the running standard scaler, run by the REFERENCE
+    code (events.py:610-866 incl. Articulation.write_*_to_sim, event_manager.py:147-225, curriculums.py:26-55 +
+    terrain_importer.py:307-324, my_running_standard_scaler.py) on duck-typed assets with injected random draws."""
+    ev = R.load_by_path("_ref_events", os.path.join(R.LAB, "isaaclab", "envs", "mdp", "events.py"))
+    art = R.ref_import("isaaclab.assets.articulation.articulation")
+    em = R.ref_import("isaaclab.managers.event_manager")
+    g = torch.Generator().manual_seed(4242)
+    n, j, b = 48, 12, 17
+    out = {}
+
+    class View:
+        def __init__(self):
+            self.calls = {}
+
+        def _set(self, name):
+            def f(data, indices=None):
+                self.calls[name] = (data.clone(), None if indices is None else torch.as_tensor(indices).clone())
+            return f
+
+        def __getattr__(self, name):
+            if name.startswith("set_"):
+                return self._set(name)
+            raise AttributeError(name)
+
+    def make_asset():
+        d = _NS(
+            default_root_state=torch.cat([torch.randn(n, 3, generator=g), rand_quat(g, n), torch.randn(n, 6, generator=g) * 0.1], dim=1),
+            root_state_w=torch.randn(n, 13, generator=g), body_acc_w=torch.randn(n, b, 6, generator=g),
+            default_joint_pos=torch.randn(n, j, generator=g) * 0.6, default_joint_vel=torch.randn(n, j, generator=g) * 0.3,
+            soft_joint_pos_limits=torch.stack([-0.9 * torch.ones(n, j), 1.1 * torch.ones(n, j)], dim=-1),
+            soft_joint_vel_limits=torch.full((n, j), 0.4),
+            joint_pos=torch.randn(n, j, generator=g), joint_vel=torch.randn(n, j, generator=g),
+            _previous_joint_vel=torch.randn(n, j, generator=g), joint_acc=torch.randn(n, j, generator=g),
+            _body_state_w=_NS(timestamp=1.0), _body_link_state_w=_NS(timestamp=1.0), _body_com_state_w=_NS(timestamp=1.0))
+        d.root_vel_w = d.root_state_w[:, 7:13]
+        asset = _NS(_data=d, data=d, device="cpu", root_physx_view=View(), _ALL_INDICES=torch.arange(n))
+        for name in ("write_root_pose_to_sim", "write_root_velocity_to_sim", "write_joint_state_to_sim"):
+            setattr(asset, name, types.MethodType(getattr(art.Articulation, name), asset))
+        return asset, d
+
+    origins = torch.randn(n, 3, generator=g) * 5.0
+    ids = torch.tensor(sorted(torch.randperm(n, generator=g)[:19].tolist()))
+    out["env_origins"], out["ids"] = origins, ids
+
+    # -- reset_root_state_uniform
+    asset, d = make_asset()
+    env = _NS(scene=_NS(env_origins=origins, **{"__getitem__": None}), num_envs=n, device="cpu")
+    scene = type("Scene", (dict,), {})(robot=asset)
+    scene.env_origins = origins
+    env.scene = scene
+    pose_range = {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "yaw": (-3.14, 3.14), "roll": (-0.3, 0.2)}
+    vel_range = {"x": (-0.5, 0.5), "y": (-0.5, 0.5), "z": (-0.5, 0.5), "roll": (-0.5, 0.5), "pitch": (-0.5, 0.5), "yaw": (-0.5, 0.5)}
+    u = torch.rand(n, 12, generator=g)
+    out.update(root_default=d.default_root_state.clone(), root_state_in=d.root_state_w.clone(), root_u=u)
+    with _RandQueue(rand=[u[ids, :6], u[ids, 6:]]):
+        ev.reset_root_state_uniform(env, ids, pose_range, vel_range)
+    out.update(root_state_out=d.root_state_w.clone(), root_body_acc_out=d.body_acc_w.clone(),
+               root_sim_transforms=asset.root_physx_view.calls["set_root_transforms"][0],
+               root_sim_velocities=asset.root_physx_view.calls["set_root_velocities"][0])
+
+    # -- reset_joints_by_scale / by_offset
+    for tag, fn, prange, vrange in (("scale", ev.reset_joints_by_scale, (0.5, 1.5), (0.0, 0.0)),
+                                    ("offset", ev.reset_joints_by_offset, (-0.4, 0.7), (-0.6, 0.5))):
+        asset, d = make_asset()
+        scene["robot"] = asset
+        u = torch.rand(n, 2 * j, generator=g)
+        out.update({f"joints_{tag}_default_pos": d.default_joint_pos.clone(), f"joints_{tag}_default_vel": d.default_joint_vel.clone(),
+                    f"joints_{tag}_pos_in": d.joint_pos.clone(), f"joints_{tag}_vel_in": d.joint_vel.clone(),
+                    f"joints_{tag}_u": u, f"joints_{tag}_pos_limits": d.soft_joint_pos_limits.clone(),
+                    f"joints_{tag}_vel_limits": d.soft_joint_vel_limits.clone()})
+        with _RandQueue(rand=[u[ids, :j], u[ids, j:]]):
+            fn(env, ids, prange, vrange)
+        out.update({f"joints_{tag}_pos_out": d.joint_pos.clone(), f"joints_{tag}_vel_out": d.joint_vel.clone(),
+                    f"joints_{tag}_prev_vel_out": d._previous_joint_vel.clone(), f"joints_{tag}_acc_out": d.joint_acc.clone(),
+                    f"joints_{tag}_sim_pos": asset.root_physx_view.calls["set_dof_positions"][0],
+                    f"joints_{tag}_sim_vel": asset.root_physx_view.calls["set_dof_velocities"][0]})
+
+    # -- push_by_setting_velocity
+    asset, d = make_asset()
+    scene["robot"] = asset
+    u = torch.rand(n, 6, generator=g)
+    out.update(push_state_in=d.root_state_w.clone(), push_u=u)
+    with _RandQueue(rand=[u[ids]]):
+        ev.push_by_setting_velocity(env, ids, {"x": (-0.5, 0.5), "y": (-0.5, 0.5)})
+    out.update(push_state_out=d.root_state_w.clone(), push_sim_velocities=asset.root_physx_view.calls["set_root_velocities"][0])
+
+    # -- EventManager.apply(mode="interval"), per-env timers (event_manager.py:199-225)
+    calls = []
+    mgr = em.EventManager.__new__(em.EventManager)
+    mgr._env = _NS(num_envs=n, device="cpu")
+    cfg = _NS(func=lambda env, env_ids, **kw: calls.append(env_ids.clone()), params={}, interval_range_s=(10.0, 15.0),
+              is_global_time=False, min_step_count_between_reset=0)
+    mgr._mode_term_names = {"interval": ["push"]}
+    mgr._mode_term_cfgs = {"interval": [cfg]}
+    tl = torch.rand(n, generator=g) * 0.07
+    tl[3] = 0.02                     # exactly dt: fires (0.02 - 0.02 < 1e-6)
+    mgr._interval_term_time_left = [tl.clone()]
+    out["interval_time_left_in"] = tl.clone()
+    fired_all, tl_all, u_all = [], [], []
+    for k in range(4):
+        u = torch.rand(n, generator=g)
+        valid = ((mgr._interval_term_time_left[0] - 0.02) < 1e-6).nonzero().flatten()
+        calls.clear()
+        with _RandQueue(rand=[u[valid]] if len(valid) else []):
+            mgr.apply(mode="interval", dt=0.02)
+        fired = torch.zeros(n, dtype=torch.bool)
+        if calls:
+            fired[calls[0]] = True
+        fired_all.append(fired); tl_all.append(mgr._interval_term_time_left[0].clone()); u_all.append(u)
+    out.update(interval_fired=torch.stack(fired_all), interval_time_left_out=torch.stack(tl_all), interval_u=torch.stack(u_all))
+
+    # -- terrain_levels_vel + TerrainImporter.update_env_origins
+    cur = R.load_by_path("_ref_curriculums", os.path.join(R.TASKS, "manager_based", "locomotion", "velocity", "mdp", "curriculums.py"))
+    ti = R.ref_import("isaaclab.terrains.terrain_importer")
+    rows, cols = 4, 5
+    t_origins = torch.randn(rows, cols, 3, generator=g) * 8.0
+    levels = torch.randint(0, rows, (n,), generator=g)
+    types_ = torch.randint(0, cols, (n,), generator=g)
+    eo = t_origins[levels, types_].clone()
+    terrain = _NS(cfg=_NS(terrain_generator=_NS(size=(8.0, 8.0))), terrain_origins=t_origins, terrain_levels=levels.clone(),
+                  terrain_types=types_, max_terrain_level=rows, env_origins=eo)
+    terrain.update_env_origins = types.MethodType(ti.TerrainImporter.update_env_origins, terrain)
+    root = torch.zeros(n, 13)
+    root[:, :2] = eo[:, :2] + (torch.rand(n, 2, generator=g) - 0.5) * 14.0
+    command = (torch.rand(n, 3, generator=g) - 0.5) * 1.2
+    robot = _NS(data=_NS(root_pos_w=root[:, :3]))
+    scene2 = type("Scene", (dict,), {})(robot=robot)
+    scene2.terrain, scene2.env_origins = terrain, eo
+    env2 = _NS(scene=scene2, command_manager=_NS(get_command=lambda name: command), max_episode_length_s=20.0)
+    rnd = torch.randint(0, rows, (n,), generator=g)
+    out.update(cur_terrain_origins=t_origins, cur_levels_in=levels.clone(), cur_types=types_, cur_env_origins_in=eo.clone(),
+               cur_root_state=root, cur_command=command, cur_random_levels=rnd)
+    with _RandQueue(randint=[rnd[ids]]):
+        state = cur.terrain_levels_vel(env2, ids)
+    out.update(cur_levels_out=terrain.terrain_levels.clone(), cur_env_origins_out=eo.clone(), cur_state=state.reshape(1))
+
+    # -- running standard scaler (my_code/models/my_running_standard_scaler.py)
+    skrl = R._stub("skrl")
+    skrl.config = _NS(torch=_NS(parse_device=lambda d: torch.device("cpu")))
+    sp = R._stub("skrl.utils.spaces.torch")
+    sp.compute_space_size = lambda size, occupied_size=True: int(size)
+    R._stub("skrl.utils"); R._stub("skrl.utils.spaces")
+    rs = R.load_by_path("_ref_scaler", os.path.join(R.REF_ROOT, "my_code", "models", "my_running_standard_scaler.py"))
+    dsz = 29
+    sc = rs.my_RunningStandardScaler(dsz, device="cpu")
+    scale = torch.rand(dsz, generator=g) * 20.0 + 0.01
+    xs = [torch.randn(65, dsz, generator=g) * scale + torch.randn(dsz, generator=g) * 4.0 for _ in range(3)]
+    xs[1][2, :4] = 1e6
+    ys = []
+    for x in xs:
+        ys.append(sc._compute(x, train=True).clone())
+    x3 = torch.stack(xs[:2])
+    y3 = sc._compute(x3, train=True).clone()
+    inv = sc._compute(ys[0], inverse=True).clone()
+    out.update(scaler_x=torch.stack(xs), scaler_y=torch.stack(ys), scaler_y3=y3, scaler_inverse=inv,
+               scaler_mean=sc.running_mean.clone(), scaler_var=sc.running_variance.clone(),
+               scaler_count=sc.current_count.reshape(1).clone())
+    save("events", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
-             "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand}
+             "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
+             "events": gen_events}
     for w in which:
         table[w]()
