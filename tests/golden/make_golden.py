@@ -1083,10 +1083,42 @@ def gen_events():
     save("events", **out)
 
 
+def gen_terrains():
+    """Height-field sub-terrains by the reference (hf_terrains.py + height_field/utils.py), trimesh.Trimesh replaced by a
+    recorder of (vertices, faces); np.random seeded before the random terrain."""
+    hf = R.ref_import("isaaclab.terrains.height_field.hf_terrains")
+    ut = R.ref_import("isaaclab.terrains.height_field.utils")
+
+    class Rec:
+        def __init__(self, vertices=None, faces=None, **kw):
+            self.vertices, self.faces = np.asarray(vertices), np.asarray(faces)
+
+    ut.trimesh = _NS(Trimesh=Rec)
+    base = dict(size=(6.0, 5.0), horizontal_scale=0.1, vertical_scale=0.005, slope_threshold=0.75)
+    cases = {
+        "random": (hf.random_uniform_terrain, 0.3, dict(border_width=0.25, noise_range=(0.02, 0.10), noise_step=0.02, downsampled_scale=None)),
+        "random_ds": (hf.random_uniform_terrain, 0.3, dict(border_width=0.0, noise_range=(-0.05, 0.05), noise_step=0.01, downsampled_scale=0.2)),
+        "slope": (hf.pyramid_sloped_terrain, 0.7, dict(border_width=0.25, slope_range=(0.0, 0.4), platform_width=2.0, inverted=False)),
+        "slope_inv": (hf.pyramid_sloped_terrain, 0.45, dict(border_width=0.25, slope_range=(0.0, 0.4), platform_width=2.0, inverted=True)),
+        "stairs": (hf.pyramid_stairs_terrain, 0.6, dict(border_width=0.5, step_height_range=(0.05, 0.23), step_width=0.3, platform_width=1.5, inverted=False)),
+        "stairs_inv": (hf.pyramid_stairs_terrain, 0.2, dict(border_width=0.5, step_height_range=(0.05, 0.23), step_width=0.3, platform_width=1.5, inverted=True)),
+    }
+    out = {}
+    for k, (name, (fn, difficulty, extra)) in enumerate(cases.items()):
+        cfg = _NS(**base, **extra)
+        np.random.seed(100 + k)
+        meshes, origin = fn(difficulty, cfg)
+        out[name + "_vertices"] = meshes[0].vertices.astype(np.float32)
+        out[name + "_faces"] = meshes[0].faces.astype(np.int32)
+        out[name + "_origin"] = np.asarray(origin, np.float64)
+        out[name + "_difficulty"] = np.array([difficulty])
+    save("terrains", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
              "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
-             "events": gen_events}
+             "events": gen_events, "terrains": gen_terrains}
     for w in which:
         table[w]()
