@@ -59,12 +59,14 @@ class ObsNormalizerStats:
         self.mean = torch.zeros(dim, dtype=torch.float64, device=self.device)
         self.var = torch.ones(dim, dtype=torch.float64, device=self.device)
         self.count = torch.ones((), dtype=torch.float64, device=self.device)
-        self._partial = torch.zeros(1 + 2 * dim, dtype=torch.float64, device=self.device)
+        self.num_chunks = 32
+        self._partial = torch.zeros((self.num_chunks, 1 + 2 * dim), dtype=torch.float64, device=self.device)
 
     def local_partial(self, obs: torch.Tensor) -> torch.Tensor:
+        """(num_chunks, 1 + 2D) Chan-mergeable partial rows of this rank's batch (``mdp_stats_moments_chunked``)."""
         obs, ld = L.rows(obs, "obs")
-        L.check(L.lib.mdp_stats_moments(obs.data_ptr(), obs.shape[0], self.dim, ld, self._partial.data_ptr(),
-                                        L.stream(self.device)))
+        L.check(L.lib.mdp_stats_moments_chunked(obs.data_ptr(), obs.shape[0], self.dim, ld, self.num_chunks,
+                                                self._partial.data_ptr(), L.stream(self.device)))
         return self._partial
 
     def update(self, obs: torch.Tensor):
@@ -76,9 +78,9 @@ class ObsNormalizerStats:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
             gathered = [torch.empty_like(part) for _ in range(dist.get_world_size(self.group))]
             dist.all_gather(gathered, part, group=self.group)
-            parts = torch.stack(gathered)
+            parts = torch.cat([p.reshape(-1, p.shape[-1]) for p in gathered])
         else:
-            parts = part[None]
+            parts = part.reshape(-1, part.shape[-1])
         n, mean, var = merge_moments(parts)
         self.mean, self.var, self.count = running_update(self.mean, self.var, self.count, mean, var, n)
 

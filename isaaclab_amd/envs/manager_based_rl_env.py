@@ -299,7 +299,7 @@ class ManagerBasedRLEnv:
                 self._post_reset_sums = torch.zeros(1 + rows * ((self.num_envs + 7) // 8), dtype=torch.float64,
                                                     device=self.device)
                 self._post_reset_log = torch.zeros(rows, dtype=torch.float32, device=self.device)
-            _, count, _, blob, sarr, scount = self._post_reset_plan
+            _, count, _, blob = self._post_reset_plan
             ra = L.MdpPostResetArgs()
             ra.fills, ra.num_fills, ra.max_episode_length_s = blob.data_ptr(), count, float(self.max_episode_length_s)
             ra.log_sums, ra.log = self._post_reset_sums.data_ptr(), self._post_reset_log.data_ptr()
@@ -363,7 +363,7 @@ class ManagerBasedRLEnv:
     def _masked_reset_plan(self, separate_sensor=None):
         """The per-env state ``_reset_idx`` zeroes, as ``mdp_fill_t`` records (built once).  Raises
         ``NotImplementedError`` for state this path does not know how to reset.  ``separate_sensor``: its three
-        bookkeeping arrays go to a second table (the post-physics launch resets them in a call of their own)."""
+        bookkeeping arrays stay out of the table (``mdp_raycaster_update_flagged`` resets them after the launch)."""
         import ctypes as C
         import struct
 
@@ -403,15 +403,11 @@ class ManagerBasedRLEnv:
                     pass                                      # stateless
                 else:
                     raise NotImplementedError(f"masked reset of actuator {type(act).__name__}")
-        sensor_fills = []
         for sensor in self.scene.sensors.values():
-            first = len(fills)
-            add_rows(sensor._timestamp)
-            add_rows(sensor._timestamp_last_update)
-            add_rows(sensor._is_outdated, 1)
-            if sensor is separate_sensor:
-                sensor_fills = fills[first:]
-                del fills[first:]
+            if sensor is not separate_sensor:
+                add_rows(sensor._timestamp)
+                add_rows(sensor._timestamp_last_update)
+                add_rows(sensor._is_outdated, 1)
             if isinstance(sensor, ContactSensor):
                 d = sensor.data
                 add_rows(d.net_forces_w)
@@ -455,10 +451,10 @@ class ManagerBasedRLEnv:
         arr = (L.MdpFill * len(fills))(*fills)
         if separate_sensor is None:
             return arr, len(fills), keep
-        # device copy of the table for the post-physics launch + the sensor's own table
+        # device copy of the table for the post-physics launch (the separated sensor is reset by
+        # mdp_raycaster_update_flagged, which needs no table)
         blob = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-        sarr = (L.MdpFill * max(len(sensor_fills), 1))(*sensor_fills)
-        return arr, len(fills), keep, blob, sarr, len(sensor_fills)
+        return arr, len(fills), keep, blob
 
     def _reset_masked(self, mask: torch.Tensor):
         """``_reset_idx`` for the envs flagged in ``mask`` (``reset_buf``) with no host synchronisation: statistics as
