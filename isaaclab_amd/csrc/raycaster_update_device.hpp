@@ -158,22 +158,28 @@ __device__ __forceinline__ void raycaster_update_flagged_blocks(const RaycasterU
     const mdp_height_scan_obs_t& scan = a.scan;
     uint64_t seed = 0, epoch = 0;
     const int base = (int)block * RCF_ENVS;
+    // the launch is a chain of dependent cold loads for the few envs it casts: everything whose address is known up
+    // front is requested together with the flags (pose, drift, generator words) instead of behind them
+    if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + block]; }
     if ((int)threadIdx.x < RCF_ENVS) {
         const int le = threadIdx.x, e = base + le;
         bool od = false;
         if (e < N) {
+            const float* p = a.pose + (int64_t)e * a.ld_pose;
+            V3 pos = ld3(p);
+            Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+            V3 dr{0.0f, 0.0f, 0.0f};
+            if (a.drift) dr = ld3(a.drift + 3 * (int64_t)e);
+            const bool reset = a.reset_mask && a.reset_mask[e];
             od = a.outdated[e] != 0;
             float t_now = a.ts[e];
-            if (a.reset_mask && a.reset_mask[e]) {       // sensor_base.py:182-195
+            if (reset) {                                  // sensor_base.py:182-195
                 t_now = 0.0f;
                 a.ts[e] = 0.0f;
                 od = true;
             }
             if (od) {
-                const float* p = a.pose + (int64_t)e * a.ld_pose;
-                V3 pos = ld3(p);
-                if (a.drift) { pos.x += a.drift[3 * e]; pos.y += a.drift[3 * e + 1]; pos.z += a.drift[3 * e + 2]; }
-                Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+                if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
                 Q4 qr = yaw_quat(q);
                 float* se = s_fenv[le];
                 se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
@@ -190,7 +196,6 @@ __device__ __forceinline__ void raycaster_update_flagged_blocks(const RaycasterU
     for (int le = 0; le < RCF_ENVS; ++le) {
         const float* se = s_fenv[le];
         if (se[5] == 0.0f) continue;                     // block-uniform
-        if (!any && scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + block]; }
         any = true;
         const V3 pos = V3{se[0], se[1], se[2]};
         const Q4 qr = Q4{se[3], 0.0f, 0.0f, se[4]};
