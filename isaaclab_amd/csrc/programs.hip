@@ -797,11 +797,11 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
         }
         // every block stores its row sums in a slot of its own (no atomics: the sums do not depend on block timing)
         double* part = a.log_sums + 1 + (size_t)b * rows;
-        for (int r0 = wave; r0 < rows; r0 += 8 * nwaves) {
-            // eight rows at a time: their loads are issued back to back, then the eight wave sums are taken
-            float v[8];
+        for (int r0 = wave; r0 < rows; r0 += 12 * nwaves) {
+            // twelve rows at a time: their loads are issued back to back, then the wave sums are taken
+            float v[12];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 12; ++j) {
                 const int r = r0 + j * nwaves;
                 v[j] = 0.0f;
                 if (mine && r < rows) {
@@ -813,7 +813,7 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < 12; ++j) {
                 const int r = r0 + j * nwaves;
                 double d = (double)v[j];
                 for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
@@ -833,19 +833,18 @@ __global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
             s_last = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull ==
                      (unsigned long long)a.nb_post;
         // the buffers _reset_idx zeroes, for the done envs of this block (mdp_fill_t records, see mdp_masked_fill)
-        // a wave per done env, lanes over the elements of each buffer (nothing to do in a block without done envs)
+        // (done env, buffer) pairs over the waves, lanes over the elements (nothing to do in a block without done envs)
         const int nd = s_nd;
-        for (int j = wave; j < nd; j += nwaves) {
+        for (int idx = wave; idx < nd * a.num_fills; idx += nwaves) {
+            const int j = idx / a.num_fills, fi = idx - j * a.num_fills;
             const int ee = e0 + s_list[j];
-            for (int fi = 0; fi < a.num_fills; ++fi) {
-                const mdp_fill_t& f = fills[fi];
-                const int64_t base = (int64_t)ee * f.env_stride;
-                for (int k = lane; k < f.count; k += 64) {
-                    const int64_t at = base + (int64_t)k * f.elem_stride;
-                    if (f.elem_bytes == 4) reinterpret_cast<uint32_t*>(f.ptr)[at] = (uint32_t)f.value_bits;
-                    else if (f.elem_bytes == 8) reinterpret_cast<uint64_t*>(f.ptr)[at] = f.value_bits;
-                    else reinterpret_cast<uint8_t*>(f.ptr)[at] = (uint8_t)f.value_bits;
-                }
+            const mdp_fill_t& f = fills[fi];
+            const int64_t base = (int64_t)ee * f.env_stride;
+            for (int k = lane; k < f.count; k += 64) {
+                const int64_t at = base + (int64_t)k * f.elem_stride;
+                if (f.elem_bytes == 4) reinterpret_cast<uint32_t*>(f.ptr)[at] = (uint32_t)f.value_bits;
+                else if (f.elem_bytes == 8) reinterpret_cast<uint64_t*>(f.ptr)[at] = f.value_bits;
+                else reinterpret_cast<uint8_t*>(f.ptr)[at] = (uint8_t)f.value_bits;
             }
         }
         // CommandTerm.reset (command_manager.py:120-149): metrics, counter, resample

@@ -71,6 +71,8 @@ def main():
         fn.argtypes = [C.c_void_p]
         fn.restype = C.c_int
         assert fn(buf.data_ptr()) == 0
+    # (the reset variant is followed by the conditional actuator launch: its stamps must not land in the same rows)
+    assert L.lib.mdp_debug_stamps_actuator_nets(None) == 0
     for rep in range(3):
         buf.zero_()
         torch.cuda.synchronize()
@@ -100,6 +102,7 @@ def main():
             print("           batches per ray, disjoint cells %.2f, other cells %.2f; max over each 64-ray wave: mean %.2f"
                   % (batches[dis == 1].mean(), batches[dis == 0].mean(),
                      np.mean([batches[:, w:w + 64].max(axis=1).mean() for w in (0, 64, 128)])))
+    assert L.lib.mdp_debug_stamps_actuator_nets(buf.data_ptr()) == 0
     for rep in range(3):
         buf.zero_()
         torch.cuda.synchronize()
