@@ -875,6 +875,33 @@ typedef struct {
 } mdp_curriculum_terrain_t;
 int mdp_curriculum_terrain_levels_vel(int num_envs, const mdp_curriculum_terrain_t* args, void* stream);
 
+/* Imu._update_buffers_impl (LAB/sensors/imu/imu.py:142-182; SURVEY.md 8f N4: a sensor that is pure math over the body
+ * state) for the envs flagged in is_outdated (NULL = all; the flags are cleared and timestamp_last_update = timestamp,
+ * sensor_base.py:284-293): pose of the sensor frame (offset applied), velocity of the link's centre of mass moved to
+ * the sensor, finite-difference accelerations (+ gravity bias) -- all rotated into the sensor frame. */
+typedef struct {
+    uint8_t* is_outdated;            /* (N) or NULL */
+    const float* timestamp;          /* (N) or NULL */
+    float* timestamp_last_update;    /* (N) or NULL */
+    const float* transforms;         /* (N,7) x, y, z, qx, qy, qz, qw of the body (RigidBodyView.get_transforms) */
+    const float* velocities;         /* (N,6) (get_velocities) */
+    const float* coms;               /* (N, ld_coms): centre-of-mass position in the body frame first (get_coms) */
+    int32_t ld_coms;
+    float dt;                        /* time since the previous update (imu.py:135-140) */
+    const float* offset_pos_b;       /* (N,3) */
+    const float* offset_quat_b;      /* (N,4) wxyz */
+    const float* gravity_bias_w;     /* (N,3) */
+    float* prev_lin_vel_w;           /* (N,3) in/out */
+    float* prev_ang_vel_w;           /* (N,3) in/out */
+    float* pos_w;                    /* outputs: (N,3), (N,4), 4 x (N,3) */
+    float* quat_w;
+    float* lin_vel_b;
+    float* ang_vel_b;
+    float* lin_acc_b;
+    float* ang_acc_b;
+} mdp_imu_args_t;
+int mdp_imu_update(int num_envs, const mdp_imu_args_t* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

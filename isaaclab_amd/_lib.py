@@ -202,6 +202,17 @@ class MdpCurriculumTerrain(C.Structure):
                 ("env_origins", C.c_void_p), ("injected_levels", C.c_void_p), ("rng_state", C.c_void_p)]
 
 
+class MdpImuArgs(C.Structure):
+    """Mirror of ``mdp_imu_args_t``."""
+
+    _fields_ = [("is_outdated", C.c_void_p), ("timestamp", C.c_void_p), ("timestamp_last_update", C.c_void_p),
+                ("transforms", C.c_void_p), ("velocities", C.c_void_p), ("coms", C.c_void_p), ("ld_coms", C.c_int32),
+                ("dt", C.c_float), ("offset_pos_b", C.c_void_p), ("offset_quat_b", C.c_void_p),
+                ("gravity_bias_w", C.c_void_p), ("prev_lin_vel_w", C.c_void_p), ("prev_ang_vel_w", C.c_void_p),
+                ("pos_w", C.c_void_p), ("quat_w", C.c_void_p), ("lin_vel_b", C.c_void_p), ("ang_vel_b", C.c_void_p),
+                ("lin_acc_b", C.c_void_p), ("ang_acc_b", C.c_void_p)]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -186,7 +186,57 @@ __global__ void k_terrain_levels_vel(int N, mdp_curriculum_terrain_t a) {
     org[0] = o[0]; org[1] = o[1]; org[2] = o[2];
 }
 
+// Imu._update_buffers_impl (LAB/sensors/imu/imu.py:142-182) for the outdated envs; one thread per env
+__global__ void k_imu_update(int N, mdp_imu_args_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || (a.is_outdated && !a.is_outdated[e])) return;
+    const float* t = a.transforms + 7 * (int64_t)e;            // x, y, z, qx, qy, qz, qw
+    const V3 p{t[0], t[1], t[2]};
+    const Q4 q{t[6], t[3], t[4], t[5]};
+    const V3 off = ld3(a.offset_pos_b + 3 * (int64_t)e);
+    const V3 r = quat_rotate(q, off);
+    st3(a.pos_w + 3 * (int64_t)e, V3{p.x + r.x, p.y + r.y, p.z + r.z});
+    const Q4 qs = quat_mul(q, ld4(a.offset_quat_b + 4 * (int64_t)e));
+    st4(a.quat_w + 4 * (int64_t)e, qs);
+    const float* v = a.velocities + 6 * (int64_t)e;
+    V3 lv{v[0], v[1], v[2]};
+    const V3 av{v[3], v[4], v[5]};
+    // the velocity of the link's centre of mass, moved to the sensor: v + w x R (offset - com)
+    const V3 com = ld3(a.coms + (int64_t)e * a.ld_coms);
+    const V3 arm = quat_rotate(q, V3{off.x - com.x, off.y - com.y, off.z - com.z});
+    const V3 c = cross(av, arm);
+    lv = V3{lv.x + c.x, lv.y + c.y, lv.z + c.z};
+    float* plv = a.prev_lin_vel_w + 3 * (int64_t)e;
+    float* pav = a.prev_ang_vel_w + 3 * (int64_t)e;
+    const float* g = a.gravity_bias_w + 3 * (int64_t)e;
+    const V3 la{(lv.x - plv[0]) / a.dt + g[0], (lv.y - plv[1]) / a.dt + g[1], (lv.z - plv[2]) / a.dt + g[2]};
+    const V3 aa{(av.x - pav[0]) / a.dt, (av.y - pav[1]) / a.dt, (av.z - pav[2]) / a.dt};
+    st3(a.lin_vel_b + 3 * (int64_t)e, quat_rotate_inverse(qs, lv));
+    st3(a.ang_vel_b + 3 * (int64_t)e, quat_rotate_inverse(qs, av));
+    st3(a.lin_acc_b + 3 * (int64_t)e, quat_rotate_inverse(qs, la));
+    st3(a.ang_acc_b + 3 * (int64_t)e, quat_rotate_inverse(qs, aa));
+    st3(plv, lv);
+    st3(pav, av);
+    if (a.is_outdated) {
+        a.is_outdated[e] = 0;
+        if (a.timestamp_last_update && a.timestamp) a.timestamp_last_update[e] = a.timestamp[e];
+    }
+}
+
 }  // namespace
+
+extern "C" int mdp_imu_update(int num_envs, const mdp_imu_args_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->transforms && a->velocities && a->coms && a->offset_pos_b && a->offset_quat_b && a->gravity_bias_w &&
+                    a->prev_lin_vel_w && a->prev_ang_vel_w && a->pos_w && a->quat_w && a->lin_vel_b && a->ang_vel_b &&
+                    a->lin_acc_b && a->ang_acc_b, "null pointer");
+    MDP_REQUIRE(a->dt > 0.0f, "dt must be positive (the sensor needs one update() before its data is read)");
+    MDP_REQUIRE(a->ld_coms >= 3, "coms rows must hold at least the position");
+    if (num_envs <= 0) return MDP_OK;
+    hipLaunchKernelGGL(k_imu_update, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
 
 extern "C" int mdp_curriculum_terrain_levels_vel(int num_envs, const mdp_curriculum_terrain_t* a, void* stream) {
     MDP_REQUIRE(a, "null arguments");

@@ -1083,6 +1083,40 @@ def gen_events():
     save("events", **out)
 
 
+def gen_imu():
+    """Imu._update_buffers_impl (imu.py:142-182) by the reference class on a duck-typed rigid-body view: three updates with
+    moving body state, the middle one for a subset of envs."""
+    imu = R.ref_import("isaaclab.sensors.imu.imu")
+    g = torch.Generator().manual_seed(777)
+    n = 40
+    out = {}
+    coms = torch.cat([torch.randn(n, 3, generator=g) * 0.05, rand_quat(g, n)], dim=1)
+    frames = [(torch.cat([torch.randn(n, 3, generator=g), rand_quat(g, n)[:, [1, 2, 3, 0]]], dim=1),
+               torch.randn(n, 6, generator=g)) for _ in range(3)]
+    state = {"k": 0}
+    view = _NS(count=n, get_transforms=lambda: frames[state["k"]][0].clone(), get_coms=lambda: coms.clone(),
+               get_velocities=lambda: frames[state["k"]][1].clone())
+    s = imu.Imu.__new__(imu.Imu)
+    s._view, s._device, s._num_envs = view, "cpu", n
+    s._data = _NS()
+    s._initialize_handle = s._invalidate_initialize_handle = s._prim_deletion_callback_id = None   # SensorBase.__del__
+    s._debug_vis_handle = None
+    s.cfg = _NS(offset=_NS(pos=(0.1, -0.05, 0.2), rot=tuple(rand_quat(g, 1)[0].tolist())), gravity_bias=(0.0, 0.0, 9.81))
+    imu.Imu._initialize_buffers_impl(s)
+    s._dt = 0.005
+    out.update(coms=coms, offset_pos=s._offset_pos_b, offset_quat=s._offset_quat_b, transforms=torch.stack([f[0] for f in frames]),
+               velocities=torch.stack([f[1] for f in frames]))
+    subset = torch.tensor(sorted(torch.randperm(n, generator=g)[:17].tolist()))
+    out["subset"] = subset
+    for k, ids in enumerate((torch.arange(n), subset, torch.arange(n))):
+        state["k"] = k
+        imu.Imu._update_buffers_impl(s, ids)
+        for name in ("pos_w", "quat_w", "lin_vel_b", "ang_vel_b", "lin_acc_b", "ang_acc_b"):
+            out[f"{name}_{k}"] = getattr(s._data, name).clone()
+        out[f"prev_lin_{k}"], out[f"prev_ang_{k}"] = s._prev_lin_vel_w.clone(), s._prev_ang_vel_w.clone()
+    save("imu", **out)
+
+
 def gen_terrains():
     """Height-field sub-terrains by the reference (hf_terrains.py + height_field/utils.py), trimesh.Trimesh replaced by a
     recorder of (vertices, faces); np.random seeded before the random terrain."""
@@ -1116,9 +1150,9 @@ def gen_terrains():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
              "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
-             "events": gen_events, "terrains": gen_terrains}
+             "events": gen_events, "terrains": gen_terrains, "imu": gen_imu}
     for w in which:
         table[w]()
