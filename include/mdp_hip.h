@@ -902,6 +902,36 @@ typedef struct {
 } mdp_imu_args_t;
 int mdp_imu_update(int num_envs, const mdp_imu_args_t* args, void* stream);
 
+/* FrameTransformer._update_buffers_impl (LAB/sensors/frame_transformer/frame_transformer.py:322-385): poses of
+ * num_frames target frames per env, in the world and relative to the env's source frame.  The index tables are the
+ * ones the reference resolves from the USD stage at initialisation (:133-320): rows of the rigid-body view reordered
+ * per env (per_env_indices), the source body row per env, the target body rows, and for every (env, frame) which
+ * target body it sits on (duplicate_frame_indices).  Offsets: (N,3)+(N,4) for the source, (N*F,3)+(N*F,4) for the
+ * targets, or NULL.  gate (device float, e.g. the number of outdated envs) == 0 -> the launch does nothing, like the
+ * reference, which recomputes every env as soon as one is outdated and none otherwise. */
+typedef struct {
+    const float* gate;                   /* or NULL: always run */
+    uint8_t* is_outdated;                /* (N) or NULL */
+    const float* timestamp;
+    float* timestamp_last_update;
+    const float* transforms;             /* (M,7) x, y, z, qx, qy, qz, qw: frame_physx_view.get_transforms() */
+    const int64_t* per_env_indices;      /* (M) */
+    const int64_t* source_frame_body_ids;/* (N) */
+    const int64_t* target_frame_body_ids;/* (N * unique target bodies) */
+    const int64_t* duplicate_frame_indices; /* (N * F) */
+    const float* source_offset_pos;      /* (N,3) or NULL */
+    const float* source_offset_quat;     /* (N,4) wxyz */
+    const float* target_offset_pos;      /* (N*F,3) or NULL */
+    const float* target_offset_quat;     /* (N*F,4) */
+    float* source_pos_w;                 /* (N,3) */
+    float* source_quat_w;                /* (N,4) */
+    float* target_pos_w;                 /* (N,F,3) */
+    float* target_quat_w;                /* (N,F,4) */
+    float* target_pos_source;            /* (N,F,3) */
+    float* target_quat_source;           /* (N,F,4) */
+} mdp_frame_transformer_args_t;
+int mdp_frame_transformer_update(int num_envs, int num_frames, const mdp_frame_transformer_args_t* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

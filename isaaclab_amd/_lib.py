@@ -213,6 +213,16 @@ class MdpImuArgs(C.Structure):
                 ("lin_acc_b", C.c_void_p), ("ang_acc_b", C.c_void_p)]
 
 
+class MdpFrameTransformerArgs(C.Structure):
+    """Mirror of ``mdp_frame_transformer_args_t``."""
+
+    _fields_ = [(n, C.c_void_p) for n in (
+        "gate", "is_outdated", "timestamp", "timestamp_last_update", "transforms", "per_env_indices",
+        "source_frame_body_ids", "target_frame_body_ids", "duplicate_frame_indices", "source_offset_pos",
+        "source_offset_quat", "target_offset_pos", "target_offset_quat", "source_pos_w", "source_quat_w", "target_pos_w",
+        "target_quat_w", "target_pos_source", "target_quat_source")]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -223,7 +223,69 @@ __global__ void k_imu_update(int N, mdp_imu_args_t a) {
     }
 }
 
+// FrameTransformer._update_buffers_impl (LAB/sensors/frame_transformer/frame_transformer.py:322-385): one thread per
+// (env, target frame).  Like the reference, every env is recomputed as soon as one is outdated (`gate` = number of
+// outdated envs, counted by the caller on the device); the bookkeeping is per env.
+__global__ void k_frame_transformer_update(int N, int F, mdp_frame_transformer_args_t a) {
+    if (a.gate != nullptr && *a.gate <= 0.0f) return;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * F) return;
+    const int e = idx / F, f = idx - e * F;
+    auto frame = [&](int64_t body) {
+        const float* t = a.transforms + 7 * (int64_t)a.per_env_indices[body];
+        return t;
+    };
+    // source frame (+ offset): combine_frame_transforms, math.py:749-781
+    const float* ts = frame(a.source_frame_body_ids[e]);
+    V3 sp{ts[0], ts[1], ts[2]};
+    Q4 sq{ts[6], ts[3], ts[4], ts[5]};
+    if (a.source_offset_pos) {
+        const V3 r = quat_apply(sq, ld3(a.source_offset_pos + 3 * (int64_t)e));
+        sp = V3{sp.x + r.x, sp.y + r.y, sp.z + r.z};
+        sq = quat_mul(sq, ld4(a.source_offset_quat + 4 * (int64_t)e));
+    }
+    // target frame (+ offset)
+    const float* tt = frame(a.target_frame_body_ids[a.duplicate_frame_indices[idx]]);
+    V3 tp{tt[0], tt[1], tt[2]};
+    Q4 tq{tt[6], tt[3], tt[4], tt[5]};
+    if (a.target_offset_pos) {
+        const V3 r = quat_apply(tq, ld3(a.target_offset_pos + 3 * (int64_t)idx));
+        tp = V3{tp.x + r.x, tp.y + r.y, tp.z + r.z};
+        tq = quat_mul(tq, ld4(a.target_offset_quat + 4 * (int64_t)idx));
+    }
+    // target in the source frame: subtract_frame_transforms, math.py:785-816 (quat_inv = normalised conjugate)
+    const Q4 inv = normalize4(quat_conjugate(sq), 1e-9f);
+    const Q4 rq = quat_mul(inv, tq);
+    const V3 rp = quat_apply(inv, V3{tp.x - sp.x, tp.y - sp.y, tp.z - sp.z});
+    if (f == 0) {
+        st3(a.source_pos_w + 3 * (int64_t)e, sp);
+        st4(a.source_quat_w + 4 * (int64_t)e, sq);
+        if (a.is_outdated && a.is_outdated[e]) {
+            a.is_outdated[e] = 0;
+            if (a.timestamp && a.timestamp_last_update) a.timestamp_last_update[e] = a.timestamp[e];
+        }
+    }
+    st3(a.target_pos_w + 3 * (int64_t)idx, tp);
+    st4(a.target_quat_w + 4 * (int64_t)idx, tq);
+    st3(a.target_pos_source + 3 * (int64_t)idx, rp);
+    st4(a.target_quat_source + 4 * (int64_t)idx, rq);
+}
+
 }  // namespace
+
+extern "C" int mdp_frame_transformer_update(int num_envs, int num_frames, const mdp_frame_transformer_args_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->transforms && a->per_env_indices && a->source_frame_body_ids && a->target_frame_body_ids &&
+                    a->duplicate_frame_indices && a->source_pos_w && a->source_quat_w && a->target_pos_w &&
+                    a->target_quat_w && a->target_pos_source && a->target_quat_source, "null pointer");
+    MDP_REQUIRE((a->source_offset_pos == nullptr) == (a->source_offset_quat == nullptr), "source offset: give both or neither");
+    MDP_REQUIRE((a->target_offset_pos == nullptr) == (a->target_offset_quat == nullptr), "target offset: give both or neither");
+    if (num_envs <= 0 || num_frames <= 0) return MDP_OK;
+    hipLaunchKernelGGL(k_frame_transformer_update, dim3(grid_for((int64_t)num_envs * num_frames, 128)), dim3(128), 0,
+                       as_stream(stream), num_envs, num_frames, *a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
 
 extern "C" int mdp_imu_update(int num_envs, const mdp_imu_args_t* a, void* stream) {
     MDP_REQUIRE(a, "null arguments");

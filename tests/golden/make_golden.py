@@ -1117,6 +1117,48 @@ def gen_imu():
     save("imu", **out)
 
 
+def gen_frame_transformer():
+    """FrameTransformer._update_buffers_impl (frame_transformer.py:322-385) by the reference class with hand-made index
+    tables (the USD walk that builds them is out of scope): 3 bodies per env in the view, 4 target frames on 2 bodies."""
+    ft = R.ref_import("isaaclab.sensors.frame_transformer.frame_transformer")
+    g = torch.Generator().manual_seed(31337)
+    n, bodies, nf = 24, 3, 4
+    out = {}
+    m = n * bodies
+    # the view lists bodies body-major (all envs of body 0, then body 1, ...): per_env_indices makes it env-major
+    per_env = torch.arange(m).reshape(bodies, n).t().reshape(-1)
+    source_ids = torch.arange(n) * bodies + 0
+    target_ids = (torch.arange(n)[:, None] * bodies + torch.tensor([1, 2])[None, :]).reshape(-1)      # 2 unique bodies
+    dup = (torch.arange(n)[:, None] * 2 + torch.tensor([0, 0, 1, 1])[None, :]).reshape(-1)            # 4 frames
+    s = ft.FrameTransformer.__new__(ft.FrameTransformer)
+    for name in ("_initialize_handle", "_invalidate_initialize_handle", "_prim_deletion_callback_id", "_debug_vis_handle"):
+        setattr(s, name, None)
+    s._num_envs, s._device = n, "cpu"
+    s._target_frame_names = ["a", "b", "c", "d"]
+    s._per_env_indices, s._source_frame_body_ids, s._target_frame_body_ids, s._duplicate_frame_indices = per_env, source_ids, target_ids, dup
+    s._apply_source_frame_offset = s._apply_target_frame_offset = True
+    s._source_frame_offset_pos = torch.randn(1, 3, generator=g).repeat(n, 1) * 0.1
+    s._source_frame_offset_quat = rand_quat(g, 1).repeat(n, 1)
+    s._target_frame_offset_pos = (torch.randn(nf, 3, generator=g) * 0.1).repeat(n, 1)
+    s._target_frame_offset_quat = rand_quat(g, nf).repeat(n, 1)
+    z = lambda *shape: torch.zeros(shape)
+    s._data = _NS(source_pos_w=z(n, 3), source_quat_w=z(n, 4), target_pos_w=z(n, nf, 3), target_quat_w=z(n, nf, 4),
+                  target_pos_source=z(n, nf, 3), target_quat_source=z(n, nf, 4))
+    tr = torch.cat([torch.randn(m, 3, generator=g), rand_quat(g, m)[:, [1, 2, 3, 0]]], dim=1)
+    s._frame_physx_view = _NS(get_transforms=lambda: tr.clone())
+    out.update(transforms=tr, per_env_indices=per_env, source_frame_body_ids=source_ids, target_frame_body_ids=target_ids,
+               duplicate_frame_indices=dup, source_offset_pos=s._source_frame_offset_pos, source_offset_quat=s._source_frame_offset_quat,
+               target_offset_pos=s._target_frame_offset_pos, target_offset_quat=s._target_frame_offset_quat)
+    ft.FrameTransformer._update_buffers_impl(s, torch.arange(n))
+    for name in ("source_pos_w", "source_quat_w", "target_pos_w", "target_quat_w", "target_pos_source", "target_quat_source"):
+        out[name] = getattr(s._data, name).clone()
+    s._apply_source_frame_offset = s._apply_target_frame_offset = False
+    ft.FrameTransformer._update_buffers_impl(s, torch.arange(n))
+    for name in ("source_pos_w", "target_pos_w", "target_pos_source", "target_quat_source"):
+        out["nooff_" + name] = getattr(s._data, name).clone()
+    save("frame_transformer", **out)
+
+
 def gen_terrains():
     """Height-field sub-terrains by the reference (hf_terrains.py + height_field/utils.py), trimesh.Trimesh replaced by a
     recorder of (vertices, faces); np.random seeded before the random terrain."""
@@ -1150,9 +1192,10 @@ def gen_terrains():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
              "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
-             "events": gen_events, "terrains": gen_terrains, "imu": gen_imu}
+             "events": gen_events, "terrains": gen_terrains, "imu": gen_imu,
+             "frames": gen_frame_transformer}
     for w in which:
         table[w]()
