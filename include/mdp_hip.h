@@ -932,6 +932,38 @@ typedef struct {
 } mdp_frame_transformer_args_t;
 int mdp_frame_transformer_update(int num_envs, int num_frames, const mdp_frame_transformer_args_t* args, void* stream);
 
+/* RayCasterCamera._update_buffers_impl (LAB/sensors/ray_caster/ray_caster_camera.py:257-318) for the outdated envs:
+ * camera pose = view pose combined with the offset (:415-430), rays of the pinhole pattern rotated by the full camera
+ * orientation and cast (max_dist 1e6), and the depth post-processing of the requested data types:
+ * distance_to_image_plane = x of the hit vector in the camera frame, distance_to_camera = ray length, both clipped per
+ * depth_clipping_behavior (0 "none", 1 "max": beyond max_distance or NaN -> max_distance, 2 "zero": -> 0), normals of
+ * the hit faces.  Output pointers of data types that were not requested are NULL.  frame (N, int64) counts updates. */
+typedef struct {
+    const mdp_mesh_t* mesh;
+    uint8_t* is_outdated;              /* (N) or NULL = every env */
+    const float* timestamp;
+    float* timestamp_last_update;
+    const float* view_pose;            /* (N, ld_pose): position + quaternion of the view the camera is attached to */
+    int32_t ld_pose;
+    int32_t pose_xyzw;                 /* 1: physics order (x, y, z, w); 0: (w, x, y, z) */
+    const float* offset_pos;           /* (N,3) */
+    const float* offset_quat;          /* (N,4) wxyz, world convention */
+    int32_t num_rays;
+    int32_t depth_clipping;
+    float max_distance;
+    int32_t pad0;
+    const float* ray_starts;           /* (N,R,3) camera frame */
+    const float* ray_directions;       /* (N,R,3) */
+    float* pos_w;                      /* (N,3) out */
+    float* quat_w_world;               /* (N,4) out */
+    float* ray_hits_w;                 /* (N,R,3) out */
+    float* distance_to_image_plane;    /* (N,R) or NULL */
+    float* distance_to_camera;         /* (N,R) or NULL */
+    float* normals;                    /* (N,R,3) or NULL */
+    int64_t* frame;                    /* (N) or NULL */
+} mdp_raycaster_camera_args_t;
+int mdp_raycaster_camera_update(int num_envs, const mdp_raycaster_camera_args_t* args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,6 +223,18 @@ class MdpFrameTransformerArgs(C.Structure):
         "target_quat_w", "target_pos_source", "target_quat_source")]
 
 
+class MdpRaycasterCameraArgs(C.Structure):
+    """Mirror of ``mdp_raycaster_camera_args_t``."""
+
+    _fields_ = [("mesh", C.c_void_p), ("is_outdated", C.c_void_p), ("timestamp", C.c_void_p),
+                ("timestamp_last_update", C.c_void_p), ("view_pose", C.c_void_p), ("ld_pose", C.c_int32),
+                ("pose_xyzw", C.c_int32), ("offset_pos", C.c_void_p), ("offset_quat", C.c_void_p),
+                ("num_rays", C.c_int32), ("depth_clipping", C.c_int32), ("max_distance", C.c_float), ("pad0", C.c_int32),
+                ("ray_starts", C.c_void_p), ("ray_directions", C.c_void_p), ("pos_w", C.c_void_p),
+                ("quat_w_world", C.c_void_p), ("ray_hits_w", C.c_void_p), ("distance_to_image_plane", C.c_void_p),
+                ("distance_to_camera", C.c_void_p), ("normals", C.c_void_p), ("frame", C.c_void_p)]
+
+
 class MdpNetDesc(C.Structure):
     _fields_ = [
         ("lstm_layers", C.c_int32), ("lstm_hidden", C.c_int32), ("lstm_input", C.c_int32),

@@ -561,6 +561,76 @@ k_raycaster_update_down(RaycasterUpdateArgs a, int epb, int slot_w) {
     raycaster_update_down_blocks<BATCH>(a, epb, slot_w, blockIdx.x, gridDim.x);
 }
 
+// RayCasterCamera._update_buffers_impl (ray_caster_camera.py:257-318): one thread per (env, ray) of the outdated envs.
+// The camera pose is the view pose combined with the offset (:415-430); rays are rotated by the full camera
+// orientation; depth outputs are post-processed like :285-312.  Flags are only read here: k_camera_bookkeeping clears
+// them afterwards (threads of one env sit in different blocks).
+template <int ACCEL>
+__global__ void k_raycaster_camera(mdp_mesh_view_t mesh, int N, int R, mdp_raycaster_camera_args_t a) {
+    const float inf = __builtin_inff();
+    const int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * R) return;
+    const int e = (int)(idx / R), r = (int)(idx - (int64_t)e * R);
+    if (a.is_outdated && !a.is_outdated[e]) return;
+    const float* t = a.view_pose + (int64_t)e * a.ld_pose;
+    V3 p{t[0], t[1], t[2]};
+    Q4 q = a.pose_xyzw ? Q4{t[6], t[3], t[4], t[5]} : Q4{t[3], t[4], t[5], t[6]};
+    // combine_frame_transforms(pos, quat, offset_pos, offset_quat), math.py:749-781
+    const V3 o = quat_apply(q, ld3(a.offset_pos + 3 * (int64_t)e));
+    p = V3{p.x + o.x, p.y + o.y, p.z + o.z};
+    q = quat_mul(q, ld4(a.offset_quat + 4 * (int64_t)e));
+    if (r == 0) {
+        st3(a.pos_w + 3 * (int64_t)e, p);
+        st4(a.quat_w_world + 4 * (int64_t)e, q);
+    }
+    V3 s = quat_apply(q, ld3(a.ray_starts + 3 * idx));
+    s = V3{s.x + p.x, s.y + p.y, s.z + p.z};
+    const V3 d = quat_apply(q, ld3(a.ray_directions + 3 * idx));
+    mdp_ray_t ray = mdp_rc_make_ray(s.x, s.y, s.z, d.x, d.y, d.z);
+    mdp_hit_t h = rc_query<ACCEL>(&mesh, &ray, 1e6f);
+    float depth = inf;
+    float* hit = a.ray_hits_w + 3 * idx;
+    if (h.face >= 0) {
+        depth = h.t;
+        hit[0] = s.x + h.t * d.x; hit[1] = s.y + h.t * d.y; hit[2] = s.z + h.t * d.z;
+    } else {
+        hit[0] = inf; hit[1] = inf; hit[2] = inf;
+    }
+    if (a.normals) {
+        float nx = inf, ny = inf, nz = inf;
+        if (h.face >= 0) mdp_rc_normal(mesh.tri_verts + 9 * (int64_t)h.face, &nx, &ny, &nz);
+        a.normals[3 * idx] = nx; a.normals[3 * idx + 1] = ny; a.normals[3 * idx + 2] = nz;
+    }
+    if (a.distance_to_image_plane) {
+        const Q4 inv = normalize4(quat_conjugate(q), 1e-9f);
+        float v = quat_apply(inv, V3{depth * d.x, depth * d.y, depth * d.z}).x;
+        if (a.depth_clipping == 1) {                 // "max": torch.clip(max=...) keeps NaN, then NaN -> max
+            v = tclamp_max(v, a.max_distance);
+            if (v != v) v = a.max_distance;
+        } else if (a.depth_clipping == 2) {          // "zero"
+            if (v > a.max_distance) v = 0.0f;
+            if (v != v) v = 0.0f;
+        }
+        a.distance_to_image_plane[idx] = v;
+    }
+    if (a.distance_to_camera) {
+        float v = depth;
+        if (a.depth_clipping == 1) v = tclamp_max(v, a.max_distance);
+        else if (a.depth_clipping == 2 && v > a.max_distance) v = 0.0f;
+        a.distance_to_camera[idx] = v;
+    }
+}
+
+__global__ void k_camera_bookkeeping(int N, mdp_raycaster_camera_args_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || (a.is_outdated && !a.is_outdated[e])) return;
+    if (a.frame) a.frame[e] += 1;                    // ray_caster_camera.py:260
+    if (a.is_outdated) {
+        a.is_outdated[e] = 0;
+        if (a.timestamp && a.timestamp_last_update) a.timestamp_last_update[e] = a.timestamp[e];
+    }
+}
+
 template <int BATCH>
 __global__ void __launch_bounds__(256)
 k_raycaster_update_flagged(RaycasterUpdateArgs a) {
@@ -677,6 +747,25 @@ extern "C" int mdp_raycaster_update_flagged(int num_envs, const mdp_raycaster_up
         if (!generated) ra.scan.rng = nullptr;
     }
     hipLaunchKernelGGL(k_raycaster_update_flagged<2>, dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream), ra);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_raycaster_camera_update(int num_envs, const mdp_raycaster_camera_args_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->mesh && a->view_pose && a->offset_pos && a->offset_quat && a->ray_starts && a->ray_directions &&
+                    a->pos_w && a->quat_w_world && a->ray_hits_w, "null pointer");
+    MDP_REQUIRE(a->num_rays > 0 && a->ld_pose >= 7, "bad shape");
+    MDP_REQUIRE(a->depth_clipping >= 0 && a->depth_clipping <= 2, "depth_clipping must be 0 (none), 1 (max) or 2 (zero)");
+    if (num_envs <= 0) return MDP_OK;
+    const int64_t total = (int64_t)num_envs * a->num_rays;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    hipStream_t s = as_stream(stream);
+    const mdp_mesh_view_t& v = a->mesh->view;
+    if (v.accel == 2) hipLaunchKernelGGL(k_raycaster_camera<2>, dim3(grid), dim3(256), 0, s, v, num_envs, a->num_rays, *a);
+    else if (v.accel == 1) hipLaunchKernelGGL(k_raycaster_camera<1>, dim3(grid), dim3(256), 0, s, v, num_envs, a->num_rays, *a);
+    else hipLaunchKernelGGL(k_raycaster_camera<0>, dim3(grid), dim3(256), 0, s, v, num_envs, a->num_rays, *a);
+    hipLaunchKernelGGL(k_camera_bookkeeping, dim3(grid_for(num_envs, 256)), dim3(256), 0, s, num_envs, *a);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -1159,6 +1159,62 @@ def gen_frame_transformer():
     save("frame_transformer", **out)
 
 
+def gen_camera():
+    """RayCasterCamera._update_buffers_impl (ray_caster_camera.py:257-318) by the reference class.  warp is absent, so its
+    `raycast_mesh` is replaced by the repo's CPU ray-cast oracle on the same mesh (the cast itself is pinned elsewhere,
+    DESIGN section 1); what this fixture pins is the camera pose, the ray rotation and the depth post-processing."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from isaaclab_amd.terrains import height_field as HF
+    from oracle.raycast_np import GridCaster, tri_soup
+
+    cam = R.ref_import("isaaclab.sensors.ray_caster.ray_caster_camera")
+    g = torch.Generator().manual_seed(2024)
+    np.random.seed(5)
+    meshes, _ = HF.pyramid_stairs_terrain(0.8, HF.HfPyramidStairsTerrainCfg(size=(6.0, 6.0), border_width=0.5, slope_threshold=0.75,
+                                                                             platform_width=1.5))
+    verts, faces = meshes[0].vertices, meshes[0].faces
+    caster = GridCaster(tri_soup(verts, faces))
+
+    def raycast_mesh(starts, dirs, mesh=None, max_dist=1e6, return_distance=False, return_normal=False, **kw):
+        shape = starts.shape[:-1]
+        hits, dist, normal, _ = caster.cast(starts.reshape(-1, 3).numpy(), dirs.reshape(-1, 3).numpy(), max_dist)
+        return (torch.from_numpy(hits).reshape(*shape, 3), torch.from_numpy(dist).reshape(*shape) if return_distance else None,
+                torch.from_numpy(normal).reshape(*shape, 3) if return_normal else None, None)
+
+    cam.raycast_mesh = raycast_mesh
+    n, h, w = 6, 6, 8
+    r = h * w
+    out = dict(vertices=verts, faces=faces.astype(np.int32))
+    view_pose = torch.cat([torch.tensor([3.0, 3.0, 2.5]) + torch.randn(n, 3, generator=g) * 0.5, rand_quat(g, n)], dim=1)   # wxyz
+    offset_pos = torch.randn(n, 3, generator=g) * 0.1
+    offset_quat = rand_quat(g, n)
+    dirs = torch.randn(n, r, 3, generator=g)
+    dirs = dirs / dirs.norm(dim=-1, keepdim=True)
+    starts = torch.zeros(n, r, 3)
+    out.update(view_pose=view_pose, offset_pos=offset_pos, offset_quat=offset_quat, ray_directions=dirs, ray_starts=starts)
+    for behavior in ("max", "zero", "none"):
+        s = cam.RayCasterCamera.__new__(cam.RayCasterCamera)
+        for name in ("_initialize_handle", "_invalidate_initialize_handle", "_prim_deletion_callback_id", "_debug_vis_handle"):
+            setattr(s, name, None)
+        s._device, s._frame = "cpu", torch.zeros(n, dtype=torch.long)
+        s._offset_pos, s._offset_quat = offset_pos.clone(), offset_quat.clone()
+        s._compute_view_world_poses = lambda env_ids: (view_pose[env_ids, :3].clone(), view_pose[env_ids, 3:].clone())
+        s.ray_starts, s.ray_directions, s.num_rays = starts, dirs, r
+        s.meshes = {"/m": None}
+        s.cfg = _NS(mesh_prim_paths=["/m"], data_types=["distance_to_image_plane", "distance_to_camera", "normals"],
+                    depth_clipping_behavior=behavior, max_distance=2.5, pattern_cfg=_NS(height=h, width=w))
+        s._data = _NS(pos_w=torch.zeros(n, 3), quat_w_world=torch.zeros(n, 4),
+                      output={"distance_to_image_plane": torch.zeros(n, h, w, 1), "distance_to_camera": torch.zeros(n, h, w, 1),
+                              "normals": torch.zeros(n, h, w, 3)})
+        cam.RayCasterCamera._update_buffers_impl(s, torch.arange(n))
+        out.update({f"{behavior}_image_plane": s._data.output["distance_to_image_plane"].clone(),
+                    f"{behavior}_camera": s._data.output["distance_to_camera"].clone(),
+                    f"{behavior}_normals": s._data.output["normals"].clone()})
+        if behavior == "max":
+            out.update(pos_w=s._data.pos_w.clone(), quat_w_world=s._data.quat_w_world.clone(), ray_hits_w=s.ray_hits_w.clone())
+    save("camera", **out)
+
+
 def gen_terrains():
     """Height-field sub-terrains by the reference (hf_terrains.py + height_field/utils.py), trimesh.Trimesh replaced by a
     recorder of (vertices, faces); np.random seeded before the random terrain."""
@@ -1192,10 +1248,10 @@ def gen_terrains():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
              "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
              "events": gen_events, "terrains": gen_terrains, "imu": gen_imu,
-             "frames": gen_frame_transformer}
+             "frames": gen_frame_transformer, "camera": gen_camera}
     for w in which:
         table[w]()
