@@ -75,7 +75,6 @@ class ManagerBasedRLEnv:
         self.observation_manager = ObservationManager(cfg.observations, self, seed=getattr(cfg, "seed", None))
         self.reward_manager = RewardManager(cfg.rewards, self)
         # reset / interval event terms (manager_based_env.py:131-133); tasks without an ``events`` cfg have none
-        self.seed = getattr(cfg, "seed", None)
         self.event_uniforms: dict[str, torch.Tensor] = {}     # tests: injected random numbers per event function
         self.event_manager = EventManager(getattr(cfg, "events", None), self)
         self.curriculum_manager = CurriculumManager(getattr(cfg, "curriculum", None), self)

@@ -46,7 +46,7 @@ def _state(env, key, seed_tag: int):
     st = states.get(key)
     if st is None:
         st = torch.zeros(1 + env.num_envs, dtype=torch.int64, device=env.device)
-        st[0] = (int(getattr(env, "seed", 0) or 0) * 0x9E3779B1 + seed_tag * 0x85EBCA77 + len(states) + 1) & 0x7FFFFFFFFFFFFFFF
+        st[0] = (int(getattr(getattr(env, "cfg", None), "seed", 0) or 0) * 0x9E3779B1 + seed_tag * 0x85EBCA77 + len(states) + 1) & 0x7FFFFFFFFFFFFFFF
         states[key] = st
     return st
 

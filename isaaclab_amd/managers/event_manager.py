@@ -168,7 +168,7 @@ class EventManager(ManagerBase):
                 self._interval_term_time_left.append(time_left.to(self.device).contiguous())
                 self._interval_masks.append(torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device))
                 rng = torch.zeros(1 + count, dtype=torch.int64, device=self.device)
-                rng[0] = (int(getattr(self._env, "seed", 0) or 0) * 0x9E3779B1 + 0x49564C + len(self._interval_rng)) & 0x7FFFFFFFFFFFFFFF
+                rng[0] = (int(getattr(getattr(self._env, "cfg", None), "seed", 0) or 0) * 0x9E3779B1 + 0x49564C + len(self._interval_rng)) & 0x7FFFFFFFFFFFFFFF
                 self._interval_rng.append(rng)
             elif term_cfg.mode == "reset":
                 if term_cfg.min_step_count_between_reset < 0:
