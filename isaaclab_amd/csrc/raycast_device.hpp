@@ -259,14 +259,25 @@ MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, fl
         int32_t c = cy * m->ncx + cx;
         int32_t braw = m->cell_start[c];
         int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
-        if (m->cell_recs) {
-            mdp_rc_cell_recs(m, r, b, e, braw >= 0, &best);
-        } else {
-            for (int32_t k = b; k < e; ++k) mdp_rc_consider(r, m->tri_verts, m->cell_tris[k], &best);
-        }
         float tmx = sx != 0 ? ((m->gx0 + m->cell * (float)(cx + (sx > 0 ? 1 : 0))) - r->ox) / dx : BIG;
         float tmy = sy != 0 ? ((m->gy0 + m->cell * (float)(cy + (sy > 0 ? 1 : 0))) - r->oy) / dy : BIG;
         float t_exit = tmx < tmy ? tmx : tmy;
+        if (m->cell_recs) {
+            // a slanted ray flies over most of the cells it crosses: in a cell whose records are sorted by descending
+            // zmax the first record bounds the cell from above, and a downward ray that leaves the cell still above
+            // that bound cannot hit anything registered here (a triangle reaching further is registered in the next
+            // cells too) -- one record read instead of all of them
+            int skip = 0;
+            if (braw >= 0 && r->dz < 0.0f && b < e) {
+                float t_low = t_exit < t1 ? t_exit : t1;
+                float z_low = r->oz + t_low * r->dz;
+                float z_top = m->cell_recs[12 * (int64_t)b + 10];
+                skip = z_low > z_top + (fabsf(z_top) + fabsf(z_low)) * 1e-5f + 1e-5f;
+            }
+            if (!skip) mdp_rc_cell_recs(m, r, b, e, braw >= 0, &best);
+        } else {
+            for (int32_t k = b; k < e; ++k) mdp_rc_consider(r, m->tri_verts, m->cell_tris[k], &best);
+        }
         // a hit at t is final once every cell still ahead only holds points with parameter > t
         float slack = fabsf(t_exit) * 1e-4f + 1e-2f * tstep;
         if (best.face >= 0 && best.t < t_exit - slack) break;
