@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -44,7 +45,11 @@ def parse():
     p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     p.add_argument("--config", default="anymal_c_rough",
                    help="anymal_c_rough (BASELINE metric: LSTM actuator net + height scan) | anymal_d_rough | anymal_d_flat")
-    p.add_argument("--ring", type=int, default=32, help="env-steps in the replayed frame ring (x decimation frames)")
+    p.add_argument("--ring", type=int, default=32,
+                   help="env-steps in the replayed frame ring (x decimation frames); min(ring, steps) is used")
+    p.add_argument("--regions", type=int, default=0,
+                   help="how often the timed region of exactly --steps steps is repeated (median reported); 0 = auto:"
+                        " at least 50 and about 2 s of timed work")
     p.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=128, help="env-steps of the CPU baseline sample (~15 s)")
@@ -145,7 +150,13 @@ def main():
 
     _trace(rank, "process group up")
     torch.manual_seed(1234 + rank)
-    ring = args.ring
+    K = args.steps
+    if K < 1:
+        raise SystemExit("--steps must be >= 1")
+    # The captured hipGraph holds one pass over the whole frame ring, so the ring never exceeds the timed step count;
+    # a second graph holds the K % ring steps left over: every timed step is a replayed one for any --steps.
+    ring = max(1, min(args.ring, K))
+    tail = K % ring
     env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
                                  small_terrain=args.small_terrain, inject_random=False, events=args.events)
     env.observation_manager.persistent_output = True
@@ -175,7 +186,7 @@ def main():
     torch.cuda.synchronize()
     _trace(rank, "warm-up done")
 
-    graph = None
+    graph = tail_graph = None
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -190,26 +201,44 @@ def main():
                 eager_steps(0, ring)
             graph.replay()
             torch.cuda.synchronize()
+            if tail:
+                # the frame cursor is back at the start of the ring here: the tail graph replays its first `tail` steps
+                tail_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(tail_graph, capture_error_mode="thread_local"):
+                    eager_steps(0, tail)
+                env.physics._cursor = 0            # capture moved the host cursor; replays do not depend on it
+                tail_graph.replay()
+                torch.cuda.synchronize()
         except Exception as e:  # capture is an optimisation; eager launches compute the same thing
             if rank == 0:
                 print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
+            graph = tail_graph = None
             torch.cuda.synchronize()
 
     reduce_stats = stats.reduce if os.environ.get("MDP_BENCH_SYNC_STATS") == "1" else stats.reduce_async
+    replayed = [0]
 
     def run(k_steps):
+        """Exactly ``k_steps`` env steps: whole-ring graph replays, then the tail graph (eager only without graphs)."""
         done, next_stats = 0, args.stats_every
+        replayed[0] = 0
         while done < k_steps:
-            if graph is not None and done + ring <= k_steps:
+            left = k_steps - done
+            if graph is not None and left >= ring:
                 graph.replay()
                 done += ring
+                replayed[0] += ring
+            elif tail_graph is not None and left == tail:
+                tail_graph.replay()
+                done += tail
+                replayed[0] += tail
             else:
                 env.step(actions[done % ring])
                 done += 1
             if done >= next_stats:          # end of a rollout: merge the episode statistics across ranks
                 reduce_stats()
-                next_stats += args.stats_every
+                while done >= next_stats:
+                    next_stats += args.stats_every
         reduce_stats()
 
     def barrier():
@@ -218,25 +247,40 @@ def main():
 
             dist.barrier()
 
-    K = args.steps
+    def timed_region():
+        """EXACTLY K steps between barrier + synchronize on both sides."""
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(K)
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0
+
     _trace(rank, f"graph {'captured' if graph is not None else 'unavailable'}")
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(K)
-    _trace(rank, "steps enqueued")
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    _trace(rank, "timed region done")
+    first = timed_region()
+    _trace(rank, "first timed region done")
+    # The region is repeated and the median reported: K = 20 steps are under 2 ms of GPU work, far too short for one
+    # sample of a host clock.  Every rank runs the same count (derived from rank 0's first region).
+    regions = args.regions
+    if regions <= 0:
+        est = torch.tensor([first], dtype=torch.float64, device=device)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.broadcast(est, src=0)
+        regions = int(min(2000, max(50, math.ceil(2.0 / max(float(est.item()), 1e-6)))))
+        regions = max(5, min(regions, int(30.0 / max(float(est.item()), 1e-6))))   # ... and at most ~30 s
+    times = torch.tensor([timed_region() for _ in range(regions)], dtype=torch.float64, device=device)
+    _trace(rank, "timed regions done")
     episode_stats = stats.result()      # drains the statistics collectives before anything is captured again
     _trace(rank, f"episode statistics merged ({len(episode_stats)} entries)")
     if world > 1:
         import torch.distributed as dist
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)       # a region takes as long as its slowest rank
+    times = times.cpu().numpy()
+    elapsed = float(np.median(times))
     value = world * args.envs * K / elapsed
 
     out = None
@@ -256,7 +300,11 @@ def main():
             "config": {"workload": f"{WORKLOADS[args.config]}: {args.envs} envs/GPU, 12 joints, 17 bodies, decimation 4,"
                                    f" 187-ray height scan on a {env.mesh.num_tris if hasattr(env, 'mesh') else 0}-triangle terrain,"
                                    f" ring of {ring * env.cfg.decimation} synthetic state frames",
-                       "envs_per_gpu": args.envs, "hip_graph": graph is not None,
+                       "envs_per_gpu": args.envs, "hip_graph": graph is not None and replayed[0] == K,
+                       "graph_replayed_steps": replayed[0], "graph_ring_steps": ring, "graph_tail_steps": tail,
+                       "timed_regions": int(len(times)), "region_ms_median": 1e3 * elapsed,
+                       "region_ms_p10": 1e3 * float(np.percentile(times, 10)),
+                       "region_ms_p90": 1e3 * float(np.percentile(times, 90)), "first_region_ms": 1e3 * first,
                        "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset, "events": bool(args.events), "normalize_obs": bool(args.normalize_obs),
                        "reset_envs_last_step": resets},
             "roofline": roof, "cpu_baseline": cpu,
