@@ -754,6 +754,26 @@ int mdp_post_physics_step_with_reset(int num_envs, const mdp_scene_update_t* upd
                                      const mdp_raycaster_update_args_t* cast, const mdp_post_reset_args_t* reset,
                                      void* stream);
 
+/* Allocation-free variant of mdp_post_physics_step_with_reset.  It has NO counterpart in the reference: it exists for
+ * callers that cannot allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same arguments, same kernels and bit-identical outputs, except that reset->log_sums MUST be NULL: the
+ * block-statistics workspace is a file-scope device array of the library (MDP_POST_NOALLOC_SCRATCH_DOUBLES doubles =
+ * 1 MiB + 8 B, held by every GPU the library runs on until the process ends).  The call allocates nothing and frees
+ * nothing (no hipMalloc / hipFree, no torch); its first call on a device looks the array's address up
+ * (hipGetSymbolAddress), so make that first call outside a capture (a warm-up step, as captures need anyway).
+ * Limit: 1 + (1 + Tr + 2 + Tt) * ceil(num_envs / 8) <= MDP_POST_NOALLOC_SCRATCH_DOUBLES (e.g. 65,536 envs with 16
+ * statistics rows), else MDP_ERR_INVALID with a message naming both numbers.  Every call on one GPU shares that GPU's
+ * array: the ticket word is cleared on `stream` before the launch and the slots are rewritten by the launch itself,
+ * so calls in stream order are safe, but two calls that OVERLAP on one GPU (different streams / processes' threads)
+ * race on it -- use the workspace variant there. */
+#define MDP_POST_NOALLOC_SCRATCH_DOUBLES 131073
+int mdp_post_physics_step_with_reset_noalloc(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                             const mdp_termination_reward_args_t* termination_reward,
+                                             const mdp_velocity_command_args_t* command,
+                                             const mdp_obs_args_t* observation,
+                                             const mdp_raycaster_update_args_t* cast,
+                                             const mdp_post_reset_args_t* reset, void* stream);
+
 /* RayCaster.reset(env_ids) + the lazy re-evaluation the next data access triggers (sensor_base.py:182-195, 284-293;
  * ray_caster.py:106-113, 220-260), for the envs flagged in `reset_mask` (device, num_envs bytes, may be null): their
  * timestamps go to 0 and they count as outdated; then every outdated env -- and only those -- is cast again and, with

@@ -19,6 +19,7 @@
 #include "stamps_device.hpp"
 
 #include <cstdlib>
+#include <mutex>
 #include <algorithm>
 #include <vector>
 
@@ -1299,6 +1300,60 @@ extern "C" int mdp_post_physics_step_with_reset(int num_envs, const mdp_scene_up
                                                 const mdp_post_reset_args_t* reset, void* stream) {
     MDP_REQUIRE(reset, "null reset arguments");
     return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, reset, stream);
+}
+
+// ---- the same entry point for callers that cannot allocate (HIP graph capture, serving loops): the block-statistics
+// workspace (`log_sums`) is a file-scope device array instead of a caller allocation.  Each GPU holds its own copy of the
+// array at its own address: the address is looked up once per device, with that device current, and host code only
+// ever uses that pointer (never the array's name, which is a host-side stand-in).
+static __device__ __align__(256) double scratch[MDP_POST_NOALLOC_SCRATCH_DOUBLES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+double* g_scratch_ptr[kMaxDevices] = {};
+
+int post_noalloc_scratch(double** out) {
+    int dev = -1;
+    MDP_CHECK_HIP(hipGetDevice(&dev));
+    MDP_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        double* p = nullptr;
+        MDP_CHECK_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+        MDP_REQUIRE(p != nullptr, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return MDP_OK;
+}
+}  // namespace
+
+extern "C" int mdp_post_physics_step_with_reset_noalloc(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                                        const mdp_termination_reward_args_t* tr,
+                                                        const mdp_velocity_command_args_t* command,
+                                                        const mdp_obs_args_t* observation,
+                                                        const mdp_raycaster_update_args_t* cast,
+                                                        const mdp_post_reset_args_t* reset, void* stream) {
+    MDP_REQUIRE(reset, "null reset arguments");
+    MDP_REQUIRE(tr && tr->termination && tr->reward, "null termination / reward programs");
+    MDP_REQUIRE(reset->log_sums == nullptr, "noalloc: log_sums must be NULL (the library's own scratch array is used)");
+    // workspace the launch will use: the ticket word + one slot of `rows` doubles per manager block of >= 8 envs
+    const int64_t rows = 1 + (int64_t)tr->reward->num_terms + 2 + (int64_t)tr->termination->num_terms;
+    const int64_t need = 1 + rows * (((int64_t)num_envs + 7) / 8);
+    MDP_REQUIRE(num_envs >= 0 && need <= (int64_t)MDP_POST_NOALLOC_SCRATCH_DOUBLES,
+                "noalloc: %lld envs x %lld statistics rows need %lld doubles of scratch, the static array holds %d"
+                " (use mdp_post_physics_step_with_reset with a workspace of your own)",
+                (long long)num_envs, (long long)rows, (long long)need, (int)MDP_POST_NOALLOC_SCRATCH_DOUBLES);
+    double* ws = nullptr;
+    int rc = post_noalloc_scratch(&ws);
+    if (rc != MDP_OK) return rc;
+    // The array keeps whatever the last call on this GPU left.  Only word 0 (the block ticket) must start at zero; the
+    // slots are fully rewritten by the blocks of this launch before its last block reads them.
+    MDP_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double), as_stream(stream)));
+    mdp_post_reset_args_t r = *reset;
+    r.log_sums = ws;
+    return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, &r, stream);
 }
 
 extern "C" int mdp_obs_postprocess(const mdp_term_t* term, int num_envs, float* data, int ld, uint64_t seed,

@@ -36,6 +36,7 @@ class ManagerBasedRLEnv:
         self.fold_action = True         # process_action inside the first actuator launch of the step
         # last scene.update + terminations + rewards + command + observations + height-scan cast in one launch
         self.single_launch_post_physics = True
+        self.post_reset_noalloc = False  # masked resets inside that launch: use the allocation-free entry point
         # (terminations + rewards, command) and the height-scan cast on two streams (only without a reset in between)
         self.concurrent_post_physics = torch.device(device).type == "cuda"
         if self.concurrent_post_physics:
@@ -302,9 +303,14 @@ class ManagerBasedRLEnv:
             ra = L.MdpPostResetArgs()
             ra.fills, ra.num_fills, ra.max_episode_length_s = blob.data_ptr(), count, float(self.max_episode_length_s)
             ra.log_sums, ra.log = self._post_reset_sums.data_ptr(), self._post_reset_log.data_ptr()
-            L.check(L.lib.mdp_post_physics_step_with_reset(
-                self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca), C.byref(obs_args),
-                C.byref(cast), C.byref(ra), L.stream(self.device)))
+            launch = L.lib.mdp_post_physics_step_with_reset
+            if self.post_reset_noalloc:
+                # callers that must not allocate (graph capture, serving loops): the library's own static scratch array
+                # takes the place of the workspace (mdp_post_physics_step_with_reset_noalloc; same kernels, same outputs)
+                ra.log_sums = None
+                launch = L.lib.mdp_post_physics_step_with_reset_noalloc
+            L.check(launch(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca), C.byref(obs_args),
+                           C.byref(cast), C.byref(ra), L.stream(self.device)))
             # RayCaster.reset of the done envs + their recast (the observation's lazy evaluation in the reference)
             L.check(L.lib.mdp_raycaster_update_flagged(self.num_envs, C.byref(cast), tm._dones_buf.data_ptr(),
                                                        L.stream(self.device)))
