@@ -7,9 +7,9 @@
 // hits with t >= 0 and t < max_t).  Closest hit; exact ties on t are broken by the SMALLEST face id so the
 // result is independent of traversal order (grid, BVH and the brute-force oracle agree bit for bit).
 //
-// The same source text is compiled by gcc for the CPU oracle (oracle/raycast_oracle.c includes this
-// file with MDP_RC_HOST defined) so both sides evaluate the identical expression trees with
-// -ffp-contract=off.
+// The CPU oracle (oracle/raycast_ref.c) is a separate restatement of the same published algorithm and does NOT
+// include this file; both are compiled with -ffp-contract=off, so hit distances can be compared bit for bit.
+// (MDP_RC_HOST lets host tools compile this header; nothing under oracle/ or tests/ does.)
 #pragma once
 #include <stdint.h>
 #include <math.h>

@@ -1,4 +1,5 @@
-"""ctypes wrapper of ``oracle/raycast_oracle.c`` (test infrastructure)."""
+"""ctypes wrapper of ``oracle/raycast_ref.c`` (test infrastructure; a self-contained restatement of the published
+watertight ray/triangle test -- it shares no source with ``isaaclab_amd/csrc``)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -13,16 +14,16 @@ _LIB = None
 def _lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "_build", "libraycast_oracle.so")
+        path = os.path.join(_HERE, "_build", "libraycast_ref.so")
         if not os.path.exists(path):
             raise ImportError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
         _LIB = C.CDLL(path)
-        _LIB.oracle_grid_build.restype = C.c_void_p
-        _LIB.oracle_grid_build.argtypes = [C.c_void_p, C.c_int32, C.c_float]
-        _LIB.oracle_grid_free.argtypes = [C.c_void_p]
-        _LIB.oracle_raycast_brute.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_float,
+        _LIB.rcref_bins_build.restype = C.c_void_p
+        _LIB.rcref_bins_build.argtypes = [C.c_void_p, C.c_int32, C.c_float]
+        _LIB.rcref_bins_free.argtypes = [C.c_void_p]
+        _LIB.rcref_brute.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_float,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        _LIB.oracle_raycast_grid.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+        _LIB.rcref_bins_cast.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     return _LIB
 
@@ -42,7 +43,7 @@ def raycast_brute(soup: np.ndarray, starts: np.ndarray, dirs: np.ndarray, max_di
     s = np.ascontiguousarray(starts, dtype=np.float32).reshape(-1, 3)
     d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
     hits, dist, normal, face = _outputs(s.shape[0])
-    _lib().oracle_raycast_brute(soup.ctypes.data, soup.shape[0], s.shape[0], s.ctypes.data, d.ctypes.data, max_dist,
+    _lib().rcref_brute(soup.ctypes.data, soup.shape[0], s.shape[0], s.ctypes.data, d.ctypes.data, max_dist,
                                 hits.ctypes.data, dist.ctypes.data, normal.ctypes.data, face.ctypes.data)
     return hits, dist, normal, face
 
@@ -56,18 +57,18 @@ class GridCaster:
             cell = float(np.sqrt(2.0 * ex * ey / self.soup.shape[0]))
             while (ex / cell + 2) * (ey / cell + 2) > 8e6:
                 cell *= 1.5
-        self._g = _lib().oracle_grid_build(self.soup.ctypes.data, self.soup.shape[0], cell)
+        self._g = _lib().rcref_bins_build(self.soup.ctypes.data, self.soup.shape[0], cell)
 
     def cast(self, starts, dirs, max_dist: float = 1e6, num_threads: int = 0):
         s = np.ascontiguousarray(starts, dtype=np.float32).reshape(-1, 3)
         d = np.ascontiguousarray(dirs, dtype=np.float32).reshape(-1, 3)
         hits, dist, normal, face = _outputs(s.shape[0])
-        _lib().oracle_raycast_grid(self._g, s.shape[0], s.ctypes.data, d.ctypes.data, max_dist, hits.ctypes.data,
+        _lib().rcref_bins_cast(self._g, s.shape[0], s.ctypes.data, d.ctypes.data, max_dist, hits.ctypes.data,
                                    dist.ctypes.data, normal.ctypes.data, face.ctypes.data, num_threads)
         return hits, dist, normal, face
 
     def __del__(self):
         try:
-            _lib().oracle_grid_free(self._g)
+            _lib().rcref_bins_free(self._g)
         except Exception:
             pass
