@@ -9,6 +9,7 @@ struct mdp_mesh {
     int device = 0;
     int64_t num_tris = 0;
     int64_t num_cell_refs = 0;
+    int64_t num_patch_verts = 0;       // vertices held by lattice patches (0: none found)
     int64_t device_bytes = 0;
     std::vector<int32_t> h_cell_tris;  // build-time scratch
 };

@@ -688,7 +688,7 @@ struct PostArgs {
 };
 
 template <int BATCH, bool RESET>
-__global__ void __launch_bounds__(1024) k_post_physics(PostArgs a) {
+__global__ void __launch_bounds__(256) k_post_physics(PostArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
         MDP_STAMP(0, 1);
@@ -1177,7 +1177,7 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
     static const int threads_env = [] {
         const char* v = std::getenv("MDP_POST_THREADS");
         int t = v ? std::atoi(v) : 0;      // 0: whole waves covering one cast slot group (<= 256 threads)
-        return t <= 0 ? 0 : (t < 64 ? 64 : (t > 1024 ? 1024 : (t / 64) * 64));
+        return t <= 0 ? 0 : (t < 64 ? 64 : (t > 256 ? 256 : (t / 64) * 64));   // the kernel is built for <= 256 threads
     }();
     static const int post_envs = [] {
         const char* v = std::getenv("MDP_POST_ENVS");
@@ -1277,9 +1277,9 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         MDP_REQUIRE(post_envs >= 8, "reset: the log_sums workspace is sized for blocks of >= 8 envs (MDP_POST_ENVS=%d)", post_envs);
         a.fills = reset->fills; a.num_fills = reset->num_fills; a.log = reset->log;
         a.log_sums = reset->log_sums; a.max_episode_length_s = reset->max_episode_length_s;
-        hipLaunchKernelGGL((k_post_physics<2, true>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
+        hipLaunchKernelGGL((k_post_physics<1, true>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
     } else {
-        hipLaunchKernelGGL((k_post_physics<2, false>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
+        hipLaunchKernelGGL((k_post_physics<1, false>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
     }
     MDP_LAUNCH_CHECK();
     return MDP_OK;

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <limits>
 #include <numeric>
+#include <unordered_map>
 #include <vector>
 
 using namespace mdp;
@@ -195,7 +196,7 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
         cell *= f;
         cell = std::max(cell, 1e-4);
     }
-    // memory guards: at most 8 M cells and (bounding-box estimate) 48 M cell references (48 B each)
+    // memory guards: at most 8 M cells and (bounding-box estimate) 48 M cell references (64 B each)
     const double max_cells = 8.0e6, max_refs = 48.0e6;
     for (int guard = 0; guard < 64; ++guard) {
         double cells = (ex / cell + 2) * (ey / cell + 2);
@@ -257,6 +258,8 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     }
     // ---- cell records: per cell sorted by descending zmax (ties: ascending face id), 12 floats each
     std::vector<float> recs;
+    std::vector<int32_t> cell_ref;   // {list offset, count} per cell
+    int64_t total_cell_refs = 0;
     std::vector<uint8_t> disjoint;
     {
         const size_t ncell = (size_t)ncx * ncy;
@@ -335,14 +338,166 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
             std::stable_sort(scored.begin(), scored.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
             for (int i = 0; i < n; ++i) b[i] = scored[i].second;
         }
-        recs.resize(m->h_cell_tris.size() * 12);
-        for (size_t k = 0; k < m->h_cell_tris.size(); ++k) {
-            int32_t f = m->h_cell_tris[k];
-            float* r = recs.data() + 12 * k;
-            std::memcpy(r, tv.data() + 9 * (size_t)f, 9 * sizeof(float));
-            std::memcpy(r + 9, &f, sizeof(int32_t));
-            r[10] = zmax_of[f];
-            r[11] = zmin_of[f];
+        // ---- interning: cells whose (ordered) lists are identical share one list and one run of records
+        {
+            std::vector<int32_t> uniq;                       // concatenated unique lists
+            uniq.reserve(m->h_cell_tris.size() / 4 + 16);
+            cell_ref.assign(2 * ncell, 0);
+            std::unordered_map<uint64_t, std::vector<std::pair<int32_t, int32_t>>> seen;   // hash -> (offset, count) candidates
+            seen.reserve(ncell / 4 + 16);
+            for (size_t c = 0; c < ncell; ++c) {
+                const int32_t* b = m->h_cell_tris.data() + counts[c];
+                const int32_t n = counts[c + 1] - counts[c];
+                int32_t off = 0;
+                if (n > 0) {
+                    uint64_t h = 1469598103934665603ull ^ (uint64_t)n;
+                    for (int32_t k = 0; k < n; ++k) { h ^= (uint64_t)(uint32_t)b[k]; h *= 1099511628211ull; h ^= h >> 29; }
+                    auto& cands = seen[h];
+                    bool found = false;
+                    for (const auto& cd : cands)
+                        if (cd.second == n && std::memcmp(uniq.data() + cd.first, b, sizeof(int32_t) * (size_t)n) == 0) { off = cd.first; found = true; break; }
+                    if (!found) {
+                        off = (int32_t)uniq.size();
+                        uniq.insert(uniq.end(), b, b + n);
+                        cands.emplace_back(off, n);
+                    }
+                }
+                cell_ref[2 * c] = off;
+                cell_ref[2 * c + 1] = n;
+            }
+            // the per-list "next zmax" field needs the list boundaries: walk the unique lists through their first owner
+            recs.assign(uniq.size() * MDP_RC_REC_STRIDE, 0.0f);
+            std::vector<uint8_t> done(uniq.size(), 0);
+            for (size_t c = 0; c < ncell; ++c) {
+                const int32_t off = cell_ref[2 * c], n = cell_ref[2 * c + 1];
+                if (n == 0 || done[(size_t)off]) continue;
+                done[(size_t)off] = 1;
+                for (int32_t k = 0; k < n; ++k) {
+                    const int32_t f = uniq[(size_t)off + k];
+                    float* r = recs.data() + (size_t)MDP_RC_REC_STRIDE * ((size_t)off + k);
+                    std::memcpy(r, tv.data() + 9 * (size_t)f, 9 * sizeof(float));
+                    std::memcpy(r + 9, &f, sizeof(int32_t));
+                    r[10] = zmax_of[f];
+                    r[11] = zmin_of[f];
+                    // zmax of the record behind this one in the same list (raycast_device.hpp: mdp_rec_t)
+                    r[12] = k + 1 < n ? zmax_of[uniq[(size_t)off + k + 1]] : -INFINITY;
+                }
+            }
+            total_cell_refs = (int64_t)m->h_cell_tris.size();   // before sharing: what the grid / BVH choice looks at
+            m->h_cell_tris.swap(uniq);
+        }
+    }
+    // ---- lattice patches (raycast_device.hpp: mdp_rc_patch_down).  A patch is a run of faces with the index pattern
+    // of a height-field mesh (LAB/terrains/height_field/utils.py:158-171: per lattice square (a, a+C+1, a+1) and
+    // (a, a+C, a+C+1), squares row by row, rows C vertices apart) whose vertices sit on an axis-aligned lattice.
+    std::vector<float> pverts;            // 4 floats per lattice vertex: x, y, z, flag bits
+    std::vector<int32_t> pcells;          // 8 words per coarse cell
+    float pgx0 = 0.0f, pgy0 = 0.0f, pg_inv = 0.0f;
+    int pgnx = 0, pgny = 0;
+    bool all_finite = true;
+    for (size_t i = 0; i < tv.size() && all_finite; ++i) all_finite = std::isfinite(tv[i]);
+    if (all_finite && !std::getenv("MDP_NO_LATTICE_PATCHES")) {
+        struct Patch { int a0, C, ni, nj, swap; float o_i, o_j, h; size_t voff; };
+        std::vector<Patch> patches;
+        auto idx = [&](int f, int k) { return indices[3 * (int64_t)f + k]; };
+        auto square = [&](int f, int a, int C) {
+            return f + 1 < num_tris && idx(f, 0) == a && idx(f, 1) == a + C + 1 && idx(f, 2) == a + 1 && idx(f + 1, 0) == a &&
+                   idx(f + 1, 1) == a + C && idx(f + 1, 2) == a + C + 1;
+        };
+        double h_min = 1e300;
+        for (int f = 0; f + 1 < num_tris;) {
+            const int a = idx(f, 0), C = idx(f + 1, 1) - a;
+            if (C < 3 || !square(f, a, C)) { ++f; continue; }
+            int rows = 0, ff = f;
+            for (;;) {
+                bool ok = true;
+                for (int j = 0; j < C - 1 && ok; ++j) ok = square(ff + 2 * j, a + rows * C + j, C);
+                if (!ok) break;
+                ++rows;
+                ff += 2 * (C - 1);
+            }
+            if (rows < 2) { ++f; continue; }
+            const int f0 = f;
+            f = ff;
+            auto P = [&](int i, int j) { return points + 3 * (int64_t)(a + i * C + j); };
+            const float* p00 = P(0, 0);
+            const double dix = (double)P(rows, 0)[0] - p00[0], diy = (double)P(rows, 0)[1] - p00[1];
+            const double djx = (double)P(0, C - 1)[0] - p00[0], djy = (double)P(0, C - 1)[1] - p00[1];
+            Patch pt{a, C, rows, C - 1, 0, 0.0f, 0.0f, 0.0f, 0};
+            double hi, hj, off_i, off_j;
+            if (std::fabs(dix) >= std::fabs(diy)) { pt.swap = 0; hi = dix / rows; hj = djy / (C - 1); off_i = diy; off_j = djx; pt.o_i = p00[0]; pt.o_j = p00[1]; }
+            else { pt.swap = 1; hi = diy / rows; hj = djx / (C - 1); off_i = dix; off_j = djy; pt.o_i = p00[1]; pt.o_j = p00[0]; }
+            if (!(hi > 0.0 && hj > 0.0) || std::fabs(hi - hj) > 1e-3 * hi || std::fabs(off_i) > 1e-3 * hi * rows ||
+                std::fabs(off_j) > 1e-3 * hj * (C - 1))
+                continue;                       // not an axis-aligned square lattice with increasing coordinates
+            pt.h = (float)hi;
+            pt.voff = pverts.size() / 4;
+            if (pt.voff + (size_t)(rows + 1) * C > (size_t)0x7fffffff) break;
+            h_min = std::min(h_min, hi);
+            // vertices + per-square flag: regular (the square's vertices sit on their lattice points, so its two
+            // triangles tile the nominal square), non-degenerate, and every grid cell it touches is a disjoint one
+            for (int i = 0; i <= rows; ++i)
+                for (int j = 0; j < C; ++j) {
+                    const float* v = P(i, j);
+                    int32_t flag = 0;
+                    if (i < rows && j < C - 1) {
+                        bool ok = true;
+                        float bx0 = INFINITY, by0 = INFINITY, bx1 = -INFINITY, by1 = -INFINITY;
+                        for (int di = 0; di < 2 && ok; ++di)
+                            for (int dj = 0; dj < 2 && ok; ++dj) {
+                                const float* q = P(i + di, j + dj);
+                                const double ci = pt.swap ? q[1] : q[0], cj = pt.swap ? q[0] : q[1];
+                                ok = std::fabs(ci - (pt.o_i + (double)(i + di) * hi)) <= 0.01 * hi &&
+                                     std::fabs(cj - (pt.o_j + (double)(j + dj) * hi)) <= 0.01 * hi;
+                                bx0 = std::min(bx0, q[0]); bx1 = std::max(bx1, q[0]);
+                                by0 = std::min(by0, q[1]); by1 = std::max(by1, q[1]);
+                            }
+                        if (ok) {
+                            const int cx0 = std::max(0, (int)std::floor((bx0 - pad - gx0) / cellf)), cx1 = std::min(ncx - 1, (int)std::floor((bx1 + pad - gx0) / cellf));
+                            const int cy0 = std::max(0, (int)std::floor((by0 - pad - gy0) / cellf)), cy1 = std::min(ncy - 1, (int)std::floor((by1 + pad - gy0) / cellf));
+                            for (int cy = cy0; cy <= cy1 && ok; ++cy)
+                                for (int cx = cx0; cx <= cx1 && ok; ++cx) ok = disjoint[(size_t)cy * ncx + cx] != 0;
+                        }
+                        flag = ok ? 1 : 0;
+                    }
+                    float w;
+                    std::memcpy(&w, &flag, sizeof(w));
+                    pverts.insert(pverts.end(), {v[0], v[1], v[2], w});
+                }
+            patches.push_back(pt);
+            (void)f0;
+        }
+        if (!patches.empty()) {
+            // coarse lookup table: a coarse cell names the patch that covers most of it (rays in the rest of the cell
+            // fail the patch's bounds test and take the ordinary path)
+            double G = 8.0 * h_min;
+            while ((ex / G + 2) * (ey / G + 2) > 1.0e6) G *= 2.0;
+            pgx0 = mn[0]; pgy0 = mn[1];
+            pgnx = (int)std::floor(ex / G) + 1; pgny = (int)std::floor(ey / G) + 1;
+            pg_inv = (float)(1.0 / G);
+            pcells.assign((size_t)pgnx * pgny * 8, 0);
+            for (size_t c = 0; c < (size_t)pgnx * pgny; ++c) pcells[8 * c + 3] = -1;
+            std::vector<float> best_area((size_t)pgnx * pgny, 0.0f);
+            for (const Patch& pt : patches) {
+                const double li = (double)pt.h * pt.ni, lj = (double)pt.h * pt.nj;
+                const double x0 = pt.swap ? pt.o_j : pt.o_i, y0 = pt.swap ? pt.o_i : pt.o_j;
+                const double x1 = x0 + (pt.swap ? lj : li), y1 = y0 + (pt.swap ? li : lj);
+                const int cx0 = std::max(0, (int)std::floor((x0 - pgx0) / G)), cx1 = std::min(pgnx - 1, (int)std::floor((x1 - pgx0) / G));
+                const int cy0 = std::max(0, (int)std::floor((y0 - pgy0) / G)), cy1 = std::min(pgny - 1, (int)std::floor((y1 - pgy0) / G));
+                for (int cy = cy0; cy <= cy1; ++cy)
+                    for (int cx = cx0; cx <= cx1; ++cx) {
+                        const double ax0 = std::max(x0, pgx0 + cx * G), ax1 = std::min(x1, pgx0 + (cx + 1) * G);
+                        const double ay0 = std::max(y0, pgy0 + cy * G), ay1 = std::min(y1, pgy0 + (cy + 1) * G);
+                        const float area = (float)(std::max(0.0, ax1 - ax0) * std::max(0.0, ay1 - ay0));
+                        const size_t c = (size_t)cy * pgnx + cx;
+                        if (area <= best_area[c]) continue;
+                        best_area[c] = area;
+                        int32_t* e = pcells.data() + 8 * c;
+                        const float inv_h = 1.0f / pt.h;
+                        std::memcpy(e + 0, &pt.o_i, 4); std::memcpy(e + 1, &pt.o_j, 4); std::memcpy(e + 2, &inv_h, 4);
+                        e[3] = (int32_t)pt.voff; e[4] = pt.C; e[5] = pt.ni; e[6] = pt.nj; e[7] = pt.swap;
+                    }
+            }
         }
     }
     // ---- BVH
@@ -373,12 +528,13 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     int64_t bytes = 0;
     int rc;
     float* d_tv = nullptr; int32_t* d_cs = nullptr; int32_t* d_ct = nullptr; float* d_nodes = nullptr; int32_t* d_bt = nullptr;
-    float* d_recs = nullptr;
+    float* d_recs = nullptr; float* d_pverts = nullptr; int32_t* d_pcells = nullptr;
     for (size_t c = 0; c < disjoint.size(); ++c)
-        if (disjoint[c]) counts[c] |= (int32_t)MDP_RC_CELL_DISJOINT;
-    if ((rc = upload(tv, &d_tv, &bytes)) || (rc = upload(counts, &d_cs, &bytes)) || (rc = upload(recs, &d_recs, &bytes)) ||
+        if (disjoint[c]) cell_ref[2 * c] |= (int32_t)MDP_RC_CELL_DISJOINT;
+    if ((rc = upload(tv, &d_tv, &bytes)) || (rc = upload(cell_ref, &d_cs, &bytes)) || (rc = upload(recs, &d_recs, &bytes)) ||
         (rc = upload(m->h_cell_tris, &d_ct, &bytes)) || (rc = upload(bb.nodes, &d_nodes, &bytes)) ||
-        (rc = upload(bb.order, &d_bt, &bytes))) {
+        (rc = upload(bb.order, &d_bt, &bytes)) || (rc = upload(pverts, &d_pverts, &bytes)) ||
+        (rc = upload(pcells, &d_pcells, &bytes))) {
         delete m;
         return rc;
     }
@@ -395,6 +551,13 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     v.finite = 1;
     for (size_t i = 0; i < tv.size(); ++i)
         if (!std::isfinite(tv[i])) { v.finite = 0; break; }
+    if (!pcells.empty()) {
+        v.patch_verts = d_pverts; v.patch_cells = d_pcells;
+        v.pgx0 = pgx0; v.pgy0 = pgy0; v.pg_inv = pg_inv; v.pgnx = pgnx; v.pgny = pgny;
+    } else {
+        (void)hipFree(d_pverts); (void)hipFree(d_pcells);
+    }
+    m->num_patch_verts = (int64_t)(pverts.size() / 4);
     v.gx0 = gx0; v.gy0 = gy0; v.cell = cellf; v.inv_cell = 1.0f / cellf;
     v.ncx = ncx; v.ncy = ncy;
     v.zmin = mn[2]; v.zmax = mx[2];
@@ -403,8 +566,8 @@ extern "C" int mdp_mesh_create(const float* points, int num_points, const int32_
     v.num_nodes = (int32_t)(bb.nodes.size() / 8);
     // auto: terrain-like meshes (few refs per cell on average, bounded z-extent per footprint) use the
     // grid; anything whose cell lists blow up (many overlapping layers / huge triangles) uses the BVH
-    double refs_per_cell = (double)m->num_cell_refs / ((double)ncx * ncy);
-    double refs_per_tri = (double)m->num_cell_refs / (double)num_tris;
+    double refs_per_cell = (double)total_cell_refs / ((double)ncx * ncy);
+    double refs_per_tri = (double)total_cell_refs / (double)num_tris;
     int chosen = accel;
     if (chosen == 0) chosen = (refs_per_cell <= 64.0 && refs_per_tri <= 64.0) ? 1 : 2;
     v.accel = chosen;
@@ -419,6 +582,8 @@ extern "C" int mdp_mesh_destroy(mdp_mesh_t* mesh) {
     (void)hipFree((void*)mesh->view.cell_start);
     (void)hipFree((void*)mesh->view.cell_tris);
     (void)hipFree((void*)mesh->view.cell_recs);
+    (void)hipFree((void*)mesh->view.patch_verts);
+    (void)hipFree((void*)mesh->view.patch_cells);
     (void)hipFree((void*)mesh->view.bvh_nodes);
     (void)hipFree((void*)mesh->view.bvh_tris);
     delete mesh;
@@ -555,8 +720,11 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
 }
 
 // The height-scan case of k_raycaster_update (body in raycaster_update_device.hpp, shared with the post-physics kernel)
+#ifndef MDP_RCD_MIN_WAVES
+#define MDP_RCD_MIN_WAVES 1
+#endif
 template <int BATCH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, MDP_RCD_MIN_WAVES)
 k_raycaster_update_down(RaycasterUpdateArgs a, int epb, int slot_w) {
     raycaster_update_down_blocks<BATCH>(a, epb, slot_w, blockIdx.x, gridDim.x);
 }
@@ -689,7 +857,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
         if (!generated) sc.rng = nullptr;
     }
     if (pattern_vertical_down && attach_yaw_only && mesh->view.accel == 1 && mesh->view.cell_recs) {
-        static const int batch = [] { const char* b = std::getenv("MDP_RC_BATCH"); return b ? std::atoi(b) : 2; }();
+        static const int batch = [] { const char* b = std::getenv("MDP_RC_BATCH"); return b ? std::atoi(b) : 1; }();
         RaycasterUpdateArgs ra;
         ra.mesh = mesh->view; ra.N = num_envs; ra.R = num_rays; ra.pose = root_pose; ra.ld_pose = ld_pose;
         ra.pose_xyzw = pose_xyzw; ra.drift = drift; ra.starts_l = ray_starts_local; ra.dirs_l = ray_dirs_local;
@@ -699,7 +867,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
 #define RCD_LAUNCH(B)                                                                                             \
     hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,          \
                        as_stream(stream), ra, epb, slot_w)
-        if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
+        if (batch == 1) RCD_LAUNCH(1); else if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
 #undef RCD_LAUNCH
         MDP_LAUNCH_CHECK();
         return MDP_OK;
@@ -769,3 +937,4 @@ extern "C" int mdp_raycaster_camera_update(int num_envs, const mdp_raycaster_cam
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
+

@@ -16,6 +16,7 @@
 
 #ifdef MDP_RC_HOST
 #define MDP_RC_FN static inline
+typedef struct { int32_t x, y; } int2;
 #else
 #include <hip/hip_runtime.h>
 #define MDP_RC_FN __device__ __forceinline__
@@ -25,7 +26,10 @@ typedef struct {
     // triangle soup (pre-gathered): tri_verts[9*f .. 9*f+8] = a, b, c
     const float* tri_verts;
     int32_t num_tris;
-    // uniform xy cell grid (CSR): cell_start[ncx*ncy + 1], cell_tris[...]
+    // uniform xy cell grid: cell_start[2 * cell] = {first entry of the cell's triangle list (top bit: MDP_RC_CELL_DISJOINT),
+    // number of entries}; cell_tris[...] the lists.  Cells with identical lists SHARE one list (and one run of cell
+    // records): on large faces -- stair treads, box tops, the border -- thousands of neighbouring cells name the same
+    // few records, so the rays of a scan that fall on one face read the same lines instead of private copies.
     const int32_t* cell_start;
     const int32_t* cell_tris;
     float gx0, gy0, cell, inv_cell;
@@ -42,6 +46,14 @@ typedef struct {
     // downward ray stops at the first record that lies entirely below its current best hit.
     const float* cell_recs;
     int32_t finite;  // every vertex coordinate is finite (device builder; lets vertical rays drop their zero products)
+    // optional lattice patches (device builder; vertical rays only): runs of faces that form a regular height-field
+    // lattice (two triangles per lattice square, LAB/terrains/height_field/utils.py:79-173) are also stored as their
+    // vertex lattice -- (x, y, z, flags) per vertex, 16 B, shared by the six triangles around it -- and found through a
+    // coarse xy table of 32-byte entries.  See mdp_rc_patch_down.
+    const float* patch_verts;        // 4 floats per lattice vertex
+    const int32_t* patch_cells;      // 8 words per coarse cell: {o_i, o_j, inv_h (float bits), voff, ncols, ni, nj, swap}
+    float pgx0, pgy0, pg_inv;
+    int32_t pgnx, pgny;
 } mdp_mesh_view_t;
 
 typedef struct {
@@ -49,7 +61,7 @@ typedef struct {
     int32_t face;
 } mdp_hit_t;
 
-// Top bit of a cell_start entry (device builder only; the entry's low 31 bits are the CSR offset): the triangles of the
+// Top bit of a cell_start entry's first word (the low 31 bits are the list offset): the triangles of the
 // cell have pairwise disjoint xy interiors and none projects to a segment.  A VERTICAL ray strictly inside one
 // footprint of such a cell cannot touch any other triangle of the cell, so its walk ends there whatever the record
 // order; the records of such a cell are ordered by coverage of the cell, NOT by zmax, so the zmax early exit must not
@@ -139,19 +151,24 @@ MDP_RC_FN void mdp_rc_consider(const mdp_ray_t* r, const float* tri_verts, int32
     }
 }
 
-// 12-float cell record (vertices, face id, zmax, zmin)
-typedef struct { float v[12]; } mdp_rec_t;
+// Cell record: one 64-byte line {a.xyz, b.xyz, c.xyz, face id, zmax, zmin, zmax of the NEXT record of the cell (-inf
+// after the last one), 3 spare}.  A record never straddles a 64-byte sector, and a downward walk through a zmax-sorted
+// cell knows from the record it holds whether the next one can still matter: the common vertical ray -- first record
+// hit, second one entirely below the hit -- costs exactly one sector.
+#define MDP_RC_REC_STRIDE 16
+typedef struct { float v[13]; } mdp_rec_t;
 
 MDP_RC_FN mdp_rec_t mdp_rc_load_rec(const float* rec) {
     mdp_rec_t o;
 #ifdef MDP_RC_HOST
-    for (int i = 0; i < 12; ++i) o.v[i] = rec[i];
+    for (int i = 0; i < 13; ++i) o.v[i] = rec[i];
 #else
-    const float4* q = (const float4*)rec;  // records are 16-byte aligned: three 128-bit loads
-    float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    const float4* q = (const float4*)rec;  // records are 64-byte aligned: four 128-bit loads of one line
+    float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     o.v[0] = q0.x; o.v[1] = q0.y; o.v[2] = q0.z; o.v[3] = q0.w;
     o.v[4] = q1.x; o.v[5] = q1.y; o.v[6] = q1.z; o.v[7] = q1.w;
     o.v[8] = q2.x; o.v[9] = q2.y; o.v[10] = q2.z; o.v[11] = q2.w;
+    o.v[12] = q3.x;
 #endif
     return o;
 }
@@ -190,7 +207,7 @@ MDP_RC_FN void mdp_rc_cell_recs(const mdp_mesh_view_t* m, const mdp_ray_t* r, in
         mdp_rec_t R[MDP_RC_BATCH];
         for (int i = 0; i < MDP_RC_BATCH; ++i) {
             int32_t kk = k + i < e ? k + i : e - 1;
-            R[i] = mdp_rc_load_rec(m->cell_recs + 12 * (int64_t)kk);
+            R[i] = mdp_rc_load_rec(m->cell_recs + MDP_RC_REC_STRIDE * (int64_t)kk);
         }
         for (int i = 0; i < MDP_RC_BATCH; ++i) {
             if (k + i >= e || stop) continue;
@@ -257,8 +274,9 @@ MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, fl
     if (sy != 0) { float ty = fabsf(m->cell / dy); if (ty < tstep) tstep = ty; }
     for (;;) {
         int32_t c = cy * m->ncx + cx;
-        int32_t braw = m->cell_start[c];
-        int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
+        const int2 cref = reinterpret_cast<const int2*>(m->cell_start)[c];   // one aligned 8-byte load
+        int32_t braw = cref.x;
+        int32_t b = MDP_RC_CELL_OFFSET(braw), e = b + cref.y;
         float tmx = sx != 0 ? ((m->gx0 + m->cell * (float)(cx + (sx > 0 ? 1 : 0))) - r->ox) / dx : BIG;
         float tmy = sy != 0 ? ((m->gy0 + m->cell * (float)(cy + (sy > 0 ? 1 : 0))) - r->oy) / dy : BIG;
         float t_exit = tmx < tmy ? tmx : tmy;
@@ -271,7 +289,7 @@ MDP_RC_FN mdp_hit_t mdp_rc_grid(const mdp_mesh_view_t* m, const mdp_ray_t* r, fl
             if (braw >= 0 && r->dz < 0.0f && b < e) {
                 float t_low = t_exit < t1 ? t_exit : t1;
                 float z_low = r->oz + t_low * r->dz;
-                float z_top = m->cell_recs[12 * (int64_t)b + 10];
+                float z_top = m->cell_recs[MDP_RC_REC_STRIDE * (int64_t)b + 10];
                 skip = z_low > z_top + (fabsf(z_top) + fabsf(z_low)) * 1e-5f + 1e-5f;
             }
             if (!skip) mdp_rc_cell_recs(m, r, b, e, braw >= 0, &best);
@@ -360,21 +378,24 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, 
     if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
     if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
     int32_t c = cy * m->ncx + cx;
-    const int32_t braw = m->cell_start[c];
+    const int2 cref = reinterpret_cast<const int2*>(m->cell_start)[c];   // one aligned 8-byte load
+    const int32_t braw = cref.x;
     const int disjoint = braw < 0;
-    int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
+    int32_t b = MDP_RC_CELL_OFFSET(braw), e = b + cref.y;
     const float inv_dz = 1.0f / r->dz;
     int stop = 0;
-    for (int32_t k = b; k < e && !stop; k += BATCH) {
+    int n = 1;   // the head record alone first, then BATCH at a time
+    for (int32_t k = b; k < e && !stop; k += n, n = BATCH) {
         mdp_rec_t R[BATCH];
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
+            if (i >= n) continue;
             int32_t kk = k + i < e ? k + i : e - 1;
-            R[i] = mdp_rc_load_rec(m->cell_recs + 12 * (int64_t)kk);
+            R[i] = mdp_rc_load_rec(m->cell_recs + MDP_RC_REC_STRIDE * (int64_t)kk);
         }
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
-            if (k + i >= e || stop) continue;
+            if (i >= n || k + i >= e || stop) continue;
             if (best.face >= 0) {
                 float t_reach = (R[i].v[10] - r->oz) * inv_dz;
                 if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = !disjoint; continue; }
@@ -387,10 +408,70 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, 
                     best.face = f;
                 }
             }
+            // the test the next record would fail first, made from this record's copy of its zmax: no load for it
+            if (!disjoint && best.face >= 0) {
+                float t_next = (R[i].v[12] - r->oz) * inv_dz;
+                if (t_next > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) stop = 1;
+            }
         }
     }
     return best;
 }
+// ---- lattice patches: the height-field shortcut of an EXACTLY vertical ray (d.x == d.y == 0, d.z < 0, finite mesh) ----
+// A ray over a lattice patch finds its lattice square by two multiplications, reads the square's four vertices (64 B in
+// two runs that the neighbouring rays of the scan share: ~1 vertex of new data per ray instead of a private line of cell
+// records behind a cell_start lookup) and tests the square's two triangles with the arithmetic of
+// mdp_rc_grid_down_exact, vertices in face order.  It only ACCEPTS when the ray lies strictly inside one of the two
+// footprints (all three edge functions non-zero with one sign) of a square the builder marked safe: every grid cell the
+// square touches has pairwise disjoint, non-degenerate footprints, so no other triangle of the mesh can contain the
+// point, and by the watertight edge rule (an edge shared by two triangles gives them the SAME edge-function value with
+// opposite signs) the neighbour rejects it too: the closest hit over all triangles is this one, same t bit for bit.
+// Everything else -- unsafe square, a zero edge function, a point outside both footprints (vertices moved by the
+// slope correction), a ray outside every patch -- returns 0 and the caller walks the grid cell as before.
+__device__ __forceinline__ int mdp_rc_patch_down(const mdp_mesh_view_t* m, float ox, float oy, float oz, float dz,
+                                                 float max_t, mdp_hit_t* out) {
+    const int pcx = (int)floorf((ox - m->pgx0) * m->pg_inv);
+    const int pcy = (int)floorf((oy - m->pgy0) * m->pg_inv);
+    if (pcx < 0 || pcx >= m->pgnx || pcy < 0 || pcy >= m->pgny) return 0;
+    const int4* pc = reinterpret_cast<const int4*>(m->patch_cells) + 2 * (pcy * m->pgnx + pcx);
+    const int4 c0 = pc[0], c1 = pc[1];
+    const int voff = c0.w;
+    if (voff < 0) return 0;
+    const int ncols = c1.x, ni = c1.y, nj = c1.z, swap = c1.w;
+    const float o_i = __int_as_float(c0.x), o_j = __int_as_float(c0.y), inv_h = __int_as_float(c0.z);
+    const int i = (int)floorf(((swap ? oy : ox) - o_i) * inv_h);
+    const int j = (int)floorf(((swap ? ox : oy) - o_j) * inv_h);
+    if (i < 0 || i >= ni || j < 0 || j >= nj) return 0;
+    const float4* V = reinterpret_cast<const float4*>(m->patch_verts) + (voff + i * ncols + j);
+    const float4 v00 = V[0], v01 = V[1], v10 = V[ncols], v11 = V[ncols + 1];
+    if (!(__float_as_int(v00.w) & 1)) return 0;
+    const float Sz = 1.0f / dz;
+    // face 2k = (v00, v11, v01), face 2k + 1 = (v00, v10, v11); edge functions as in mdp_rc_grid_down_exact
+    const float Ax = v00.y - oy, Ay = v00.x - ox;
+    const float Dx = v11.y - oy, Dy = v11.x - ox;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float4 b = k == 0 ? v11 : v10, c = k == 0 ? v01 : v11;
+        const float Bx = k == 0 ? Dx : v10.y - oy, By = k == 0 ? Dy : v10.x - ox;
+        const float Cx = k == 0 ? v01.y - oy : Dx, Cy = k == 0 ? v01.x - ox : Dy;
+        const float U = Cx * By - Cy * Bx;
+        const float V_ = Ax * Cy - Ay * Cx;
+        const float W = Bx * Ay - By * Ax;
+        const bool pos = U > 0.0f && V_ > 0.0f && W > 0.0f, neg = U < 0.0f && V_ < 0.0f && W < 0.0f;
+        if (!(pos || neg)) continue;
+        out->t = max_t; out->face = -1;
+        const float det = (U + V_) + W;
+        const float Az = Sz * (v00.z - oz), Bz = Sz * (b.z - oz), Cz = Sz * (c.z - oz);
+        const float T = (U * Az + V_ * Bz) + W * Cz;
+        if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) return 1;   // behind the origin: the only candidate
+        const float rcp = 1.0f / det;
+        const float t = T * rcp;
+        if (t >= 0.0f && t < max_t) { out->t = t; out->face = 0; }
+        return 1;
+    }
+    return 0;
+}
+
 // mdp_rc_grid_down for an EXACTLY vertical ray (d.x == d.y == 0, d.z < 0) on a mesh with finite vertices, with the
 // arithmetic that cannot change a result removed (the cast kernel is bound by vector instructions, not by memory):
 //   * Sx = d.y / d.z and Sy = d.x / d.z are zeros, so Sx * Az3 is a zero and Ax = Ay3 - Sx * Az3 == Ay3 bit for bit for
@@ -411,25 +492,35 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
     if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
     if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
     int32_t c = cy * m->ncx + cx;
-    const int32_t braw = m->cell_start[c];
+    const int2 cref = reinterpret_cast<const int2*>(m->cell_start)[c];   // one aligned 8-byte load
+    const int32_t braw = cref.x;
     const bool disjoint = braw < 0;
-    int32_t b = MDP_RC_CELL_OFFSET(braw), e = MDP_RC_CELL_OFFSET(m->cell_start[c + 1]);
+    int32_t b = MDP_RC_CELL_OFFSET(braw), e = b + cref.y;
     const float Sz = 1.0f / dz;
     int stop = 0;
     // diagnostic (stamp build only): 1000 * disjoint + 10 * records in the cell + batches read
     if (dbg_iters) *dbg_iters = (disjoint ? 1000 : 0) + (e - b) * 10;
-    for (int32_t k = b; k < e && !stop; k += BATCH) {
+    int n = 1;   // the head record alone first (one 64-byte sector), then BATCH at a time
+    for (int32_t k = b; k < e && !stop; k += n, n = BATCH) {
         if (dbg_iters) *dbg_iters += 1;
         mdp_rec_t R[BATCH];
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
+            if (i >= n) continue;
             int32_t kk = k + i < e ? k + i : e - 1;
-            R[i] = mdp_rc_load_rec(m->cell_recs + 12 * (int64_t)kk);
+            R[i] = mdp_rc_load_rec(m->cell_recs + MDP_RC_REC_STRIDE * (int64_t)kk);
         }
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
-            if (k + i >= e || stop) continue;
+            if (i >= n || k + i >= e || stop) continue;
             const float* tv = R[i].v;
+            // (zmax-sorted cells) the test the NEXT record would fail first, made from this record's copy of that
+            // record's zmax once this record has been tried: the next line is not loaded at all
+            #define MDP_RC_NEXT_BELOW()                                                                    \
+                if (!disjoint && best.face >= 0) {                                                         \
+                    float t_next = (tv[12] - oz) * Sz;                                                     \
+                    if (t_next > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) stop = 1;                       \
+                }
             if (best.face >= 0) {
                 float t_reach = (tv[10] - oz) * Sz;
                 if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = !disjoint; continue; }
@@ -448,19 +539,21 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
                 double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
                 W = (float)(BxAy - ByAx);
             }
-            if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) continue;
+            if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) { MDP_RC_NEXT_BELOW(); continue; }
             // strictly inside this footprint, in a cell of disjoint footprints: no other record can be touched
             if (disjoint && ((U > 0.0f && V > 0.0f && W > 0.0f) || (U < 0.0f && V < 0.0f && W < 0.0f))) stop = 1;
             float det = (U + V) + W;
-            if (det == 0.0f) continue;
+            if (det == 0.0f) { MDP_RC_NEXT_BELOW(); continue; }
             float Az = Sz * (tv[2] - oz), Bz = Sz * (tv[5] - oz), Cz = Sz * (tv[8] - oz);
             float T = (U * Az + V * Bz) + W * Cz;
-            if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) continue;
+            if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) { MDP_RC_NEXT_BELOW(); continue; }
             float rcp = 1.0f / det;
             float t = T * rcp;
             if (t >= 0.0f && t < best.t) { best.t = t; best.face = 0; }   // ties on t do not change t
+            MDP_RC_NEXT_BELOW();
         }
     }
+    #undef MDP_RC_NEXT_BELOW
     return best;
 }
 #endif  // !MDP_RC_HOST

@@ -68,7 +68,8 @@ __device__ __forceinline__ void raycaster_down_ray(const RaycasterUpdateArgs& a,
         h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &walk);
         if (g_stamps) g_stamps[8192 * 8 + (size_t)e * R + r] = (unsigned long long)walk;
 #else
-        h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist);
+        if (!(mesh.patch_cells && mdp_rc_patch_down(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &h)))
+            h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist);
 #endif
     } else {
         mdp_vray_t ray = mdp_rc_make_vray(s.x, s.y, s.z, d.x, d.y, d.z);

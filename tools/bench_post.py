@@ -6,7 +6,13 @@ import sys, os; sys.path.insert(0, '.')
 import torch
 from isaaclab_amd.envs.synthetic import make_velocity_env
 from tools.bench_stages import graph_time
-env, rec = make_velocity_env("anymal_c_rough", num_envs=4096, device="cuda:0", steps=4, seed=5, inject_random=False)
+N = int(os.environ.get("BENCH_POST_ENVS", "4096"))
+env, rec = make_velocity_env("anymal_c_rough", num_envs=N, device="cuda:0", steps=4, seed=5, inject_random=False,
+                             small_terrain=os.environ.get("BENCH_POST_SMALL") == "1")
+if os.environ.get("BENCH_POST_SAMEPOSE") == "1":      # every env at env 0's pose in every frame: all casts share lines
+    fr = env.physics._frames
+    rt = env.physics.field_view(fr, "root_transforms")
+    rt[:] = rt[:, :1]
 env.observation_manager.persistent_output = True
 acts = rec.actions.to("cuda:0")
 for k in range(4):
