@@ -102,22 +102,29 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
         const int e = base + le;
         const bool active = le < epb && e < N;
         if (active && lr == 0) {
+            // everything whose address is known up front is requested together (flags, timestamps, pose, drift): one
+            // round trip instead of flags -> pose; envs that turn out not to be outdated only wasted two lines
+            const float* p = a.pose + (int64_t)e * a.ld_pose;
+            const uint8_t od_in = a.outdated ? a.outdated[e] : (uint8_t)1;
+            const float ts_in = a.ts ? a.ts[e] : 0.0f;
+            const float last_in = (a.tick_dt > 0.0f) ? a.ts_last[e] : 0.0f;
+            V3 pos = ld3(p);
+            // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows (w, x, y, z)
+            const Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+            V3 dr{0.0f, 0.0f, 0.0f};
+            if (a.drift) dr = ld3(a.drift + 3 * (int64_t)e);
             // SensorBase.update of this physics step (sensor_base.py:197-205) + the lazy-evaluation test (:284-293)
-            bool od = a.outdated ? a.outdated[e] != 0 : true;
-            float t_now = a.ts ? a.ts[e] : 0.0f;
+            bool od = od_in != 0;
+            float t_now = ts_in;
             if (a.tick_dt > 0.0f) {
                 t_now += a.tick_dt;
                 a.ts[e] = t_now;
-                if ((t_now - a.ts_last[e]) + 1e-6f >= a.period) od = true;
+                if ((t_now - last_in) + 1e-6f >= a.period) od = true;
             }
             float* se = s_env[le];
             se[5] = od ? 1.0f : 0.0f;
             if (od) {
-                const float* p = a.pose + (int64_t)e * a.ld_pose;
-                V3 pos = ld3(p);
-                if (a.drift) { pos.x += a.drift[3 * e]; pos.y += a.drift[3 * e + 1]; pos.z += a.drift[3 * e + 2]; }
-                // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows (w, x, y, z)
-                Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+                if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
                 Q4 qr = yaw_quat(q);
                 se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
                 st3(a.pos_w + 3 * (int64_t)e, pos);
