@@ -33,7 +33,11 @@ WORKLOADS = {
     "anymal_c_rough": "Isaac-Velocity-Rough-Anymal-C-v0 MDP compute (ANYdrive LSTM actuator net, seeded random weights)",
     "anymal_d_rough": "Isaac-Velocity-Rough-Anymal-D-v0 MDP compute (DC-motor actuator)",
     "anymal_d_flat": "Isaac-Velocity-Flat-Anymal-D-v0 MDP compute (DC-motor actuator, no height scan)",
+    "h1_rough": "Isaac-Velocity-Rough-H1-v0 MDP compute (implicit actuators, per-GPU share of BASELINE configs[3])",
+    "shadow": "Isaac-Repose-Cube-Shadow-Direct-v0 MDP compute (DirectRLEnv.step order, per-GPU share of BASELINE configs[4])",
 }
+# bodies referenced by terms / feet ("Bc contact bodies actually referenced by terms")
+TERM_BODIES = {"h1_rough": (3, 2)}
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
@@ -42,9 +46,11 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=256)
     p.add_argument("--warmup", type=int, default=32)
-    p.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    p.add_argument("--envs", type=int, default=0,
+                   help="envs per GPU (default: 4096; h1_rough 8192 and shadow 16384 = their per-GPU share)")
     p.add_argument("--config", default="anymal_c_rough",
-                   help="anymal_c_rough (BASELINE metric: LSTM actuator net + height scan) | anymal_d_rough | anymal_d_flat")
+                   help="anymal_c_rough (BASELINE metric: LSTM actuator net + height scan) | anymal_d_rough | anymal_d_flat"
+                        " | h1_rough | shadow")
     p.add_argument("--ring", type=int, default=32,
                    help="env-steps in the replayed frame ring (x decimation frames); min(ring, steps) is used")
     p.add_argument("--regions", type=int, default=0,
@@ -62,7 +68,12 @@ def parse():
                    help="also leave the standardised, clipped observation in a storage slot (not the headline metric)")
     p.add_argument("--events", action="store_true",
                    help="with --auto-reset masked: the task's reset / interval event terms and terrain curriculum too")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.config not in WORKLOADS:
+        raise SystemExit(f"unknown --config {a.config!r}: {' | '.join(WORKLOADS)}")
+    if a.envs <= 0:
+        a.envs = {"h1_rough": 8192, "shadow": 16384}.get(a.config, 4096)
+    return a
 
 
 # ---- algorithmic bytes (SURVEY.md 8d counting rules; table repeated in DESIGN.md) -------------------------
@@ -74,7 +85,7 @@ def algorithmic_bytes(env) -> dict:
     J = robot.num_joints
     D = env.cfg.decimation
     H = 3
-    Bc, Bf = 9, 4                       # bodies referenced by terms (4 feet + 4 thighs + base), feet
+    Bc, Bf = TERM_BODIES.get(getattr(env, "_bench_config", ""), (9, 4))   # term-referenced bodies (Anymal: 4 feet + 4 thighs + base), feet
     O = env.observation_manager.group_obs_dim["policy"][0]
     Tr = sum(1 for c in env.reward_manager._term_cfgs if c.weight != 0.0)
     Tt = len(env.termination_manager.active_terms)
@@ -157,23 +168,31 @@ def main():
     # a second graph holds the K % ring steps left over: every timed step is a replayed one for any --steps.
     ring = max(1, min(args.ring, K))
     tail = K % ring
-    env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
-                                 small_terrain=args.small_terrain, inject_random=False, events=args.events)
-    env.observation_manager.persistent_output = True
-    if args.auto_reset == "masked":
-        env.auto_reset = "masked"
-    if args.normalize_obs:
-        from isaaclab_amd.rl import RunningStandardScaler
+    shadow = args.config == "shadow"
+    if shadow:
+        if args.auto_reset != "off" or args.events or args.normalize_obs:
+            raise SystemExit("--auto-reset / --events / --normalize-obs belong to the velocity configs")
+        env, rec, actions = make_shadow_env(args, device, ring, seed=1234 + 1 + 1000 * rank)
+        stats = None
+    else:
+        env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
+                                     small_terrain=args.small_terrain, inject_random=False, events=args.events)
+        env._bench_config = args.config
+        env.observation_manager.persistent_output = True
+        if args.auto_reset == "masked":
+            env.auto_reset = "masked"
+        if args.normalize_obs:
+            from isaaclab_amd.rl import RunningStandardScaler
 
-        width = env.observation_manager.group_obs_dim["policy"][0]
-        env.set_obs_normalizer(RunningStandardScaler(width, device=device))
-    if "height_scanner" in env.scene.sensors:
-        env.scene.sensors["height_scanner"].fuse_into_observations = args.fuse_cast
-    # episode_length_buf ~ U{0..999}
-    g = torch.Generator().manual_seed(99 + rank)
-    env.episode_length_buf.copy_(torch.randint(0, 1000, (args.envs,), generator=g))
-    actions = rec.actions.to(device)
-    stats = EpisodeStats(env, world)
+            width = env.observation_manager.group_obs_dim["policy"][0]
+            env.set_obs_normalizer(RunningStandardScaler(width, device=device))
+        if "height_scanner" in env.scene.sensors:
+            env.scene.sensors["height_scanner"].fuse_into_observations = args.fuse_cast
+        # episode_length_buf ~ U{0..999}
+        g = torch.Generator().manual_seed(99 + rank)
+        env.episode_length_buf.copy_(torch.randint(0, 1000, (args.envs,), generator=g))
+        actions = rec.actions.to(device)
+        stats = EpisodeStats(env, world)
 
     def eager_steps(k0, count):
         for k in range(k0, k0 + count):
@@ -215,7 +234,10 @@ def main():
             graph = tail_graph = None
             torch.cuda.synchronize()
 
-    reduce_stats = stats.reduce if os.environ.get("MDP_BENCH_SYNC_STATS") == "1" else stats.reduce_async
+    if stats is None:                   # Shadow hand: its one statistic (consecutive_successes) is reduced inside the step
+        reduce_stats = lambda: None
+    else:
+        reduce_stats = stats.reduce if os.environ.get("MDP_BENCH_SYNC_STATS") == "1" else stats.reduce_async
     replayed = [0]
 
     def run(k_steps):
@@ -273,7 +295,7 @@ def main():
         regions = max(5, min(regions, int(30.0 / max(float(est.item()), 1e-6))))   # ... and at most ~30 s
     times = torch.tensor([timed_region() for _ in range(regions)], dtype=torch.float64, device=device)
     _trace(rank, "timed regions done")
-    episode_stats = stats.result()      # drains the statistics collectives before anything is captured again
+    episode_stats = stats.result() if stats is not None else {}   # drains the statistics collectives before anything is captured again
     _trace(rank, f"episode statistics merged ({len(episode_stats)} entries)")
     if world > 1:
         import torch.distributed as dist
@@ -288,18 +310,16 @@ def main():
     if getattr(env, "_post_reset_log", None) is not None:
         resets = float(env._post_reset_log[0].item())      # envs the last timed step reset (its own log count)
     if rank == 0:
-        roof = measure_roofline(env, args)
+        roof = measure_roofline_shadow(env, actions) if shadow else measure_roofline(env, args)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(rec, args)
+            cpu = cpu_baseline_shadow(rec, args) if shadow else cpu_baseline(rec, args)
         out = {
             "metric": "env-steps/sec of MDP compute (Anymal-C rough, 4096 envs/GPU) + % HBM peak",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{WORKLOADS[args.config]}: {args.envs} envs/GPU, 12 joints, 17 bodies, decimation 4,"
-                                   f" 187-ray height scan on a {env.mesh.num_tris if hasattr(env, 'mesh') else 0}-triangle terrain,"
-                                   f" ring of {ring * env.cfg.decimation} synthetic state frames",
+            "config": {"workload": workload_text(env, args, ring),
                        "envs_per_gpu": args.envs, "hip_graph": graph is not None and replayed[0] == K,
                        "graph_replayed_steps": replayed[0], "graph_ring_steps": ring, "graph_tail_steps": tail,
                        "timed_regions": int(len(times)), "region_ms_median": 1e3 * elapsed,
@@ -315,6 +335,138 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def workload_text(env, args, ring) -> str:
+    if args.config == "shadow":
+        return (f"{WORKLOADS[args.config]}: {args.envs} envs/GPU, {env.num_hand_dofs} joints, {env.hand.num_bodies} bodies,"
+                f" {env.num_fingertips} fingertips, decimation {env.cfg.decimation}, {env.num_full_obs}-wide observation,"
+                f" ring of {ring * env.cfg.decimation} synthetic state frames")
+    robot = env.scene["robot"]
+    scan = ""
+    if "height_scanner" in env.scene.sensors:
+        scan = (f" {env.scene.sensors['height_scanner'].num_rays}-ray height scan on a"
+                f" {env.mesh.num_tris if getattr(env, 'mesh', None) is not None else 0}-triangle terrain,")
+    return (f"{WORKLOADS[args.config]}: {args.envs} envs/GPU, {robot.num_joints} joints, {robot.num_bodies} bodies,"
+            f" decimation {env.cfg.decimation},{scan} ring of {ring * env.cfg.decimation} synthetic state frames")
+
+
+# ---- Shadow hand (BASELINE configs[4]): DirectRLEnv.step order over a synthetic feed -------------------------------
+def make_shadow_env(args, device, ring, seed):
+    """InHandManipulationEnv over a ring of random hand frames resident in HBM (generated on the device: the frames are
+    36 MB each at 16384 envs) and a fixed object state near the palm; returns (env, recording dict, actions)."""
+    from isaaclab_amd.tasks.inhand import InHandManipulationEnv, ShadowHandEnvCfg
+
+    n = args.envs
+    cfg = ShadowHandEnvCfg(num_envs=n)
+    g = torch.Generator(device=device).manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g, device=device)
+    u = lambda *s: torch.rand(*s, generator=g, device=device)
+    D = len(cfg.joint_names)
+    origins = r(n, 3) * 3.0
+    limits = torch.stack([-1.0 - u(n, D), 1.0 + u(n, D)], dim=-1)
+    env = InHandManipulationEnv(cfg, device, env_origins=origins, joint_pos_limits=limits)
+    view = env.hand_view
+    T = ring * cfg.decimation
+    frames = torch.zeros(T, view.frame_size, device=device)
+    lo, hi = env.hand_dof_lower_limits, env.hand_dof_upper_limits
+    for t in range(T):
+        view.field_view(frames, "dof_positions")[t] = lo + (hi - lo) * u(n, D)
+        view.field_view(frames, "dof_velocities")[t] = r(n, D)
+        lt = view.field_view(frames, "link_transforms")[t]
+        lt[..., :3] = r(n, env.hand.num_bodies, 3) * 0.1 + origins[:, None, :]
+        q = r(n, env.hand.num_bodies, 4)
+        lt[..., 3:] = q / q.norm(dim=-1, keepdim=True)
+        view.field_view(frames, "link_velocities")[t] = r(n, env.hand.num_bodies, 6)
+    view.set_frames(frames)
+    q = r(n, 4)
+    q = q / q.norm(dim=-1, keepdim=True)
+    obj_pos = r(n, 3) * 0.08 + torch.tensor(cfg.object_init_pos, device=device) + origins
+    env.object_view.transforms.copy_(torch.cat([obj_pos, q[:, 1:], q[:, :1]], dim=1))
+    env.object_view.velocities.copy_(r(n, 6))
+    goal = r(n, 4)
+    goal = goal / goal.norm(dim=-1, keepdim=True)
+    goal[::9] = q[::9]
+    env.goal_rot.copy_(goal)
+    env.episode_length_buf.copy_(torch.randint(0, 400, (n,), generator=g, device=device))
+    env.physics = view                      # the ring cursor the graph capture rewinds
+    actions = u(ring, n, cfg.action_space) * 2.0 - 1.0
+    rec = {"frames": frames, "actions": actions, "origins": origins, "limits": limits, "goal": goal,
+           "obj": torch.cat([obj_pos, q, env.object_view.velocities], dim=1), "in_hand": env.in_hand_pos,
+           "fingers": list(env.finger_bodies), "act_idx": list(env.actuated_dof_indices)}
+    return env, rec, actions
+
+
+def shadow_algorithmic_bytes(env) -> int:
+    """read 2J + 13 + 13 x fingertips + actions + episode counter, write obs + reward + flags; actuator
+    targets 20 B x J per sub-step."""
+    J, Fg, A, D = env.num_hand_dofs, env.num_fingertips, env.cfg.action_space, env.cfg.decimation
+    return 4 * (2 * J + 13 + 13 * Fg + A + 4) + 4 * (env.num_full_obs + 1 + 3) + 20 * J * D
+
+
+def measure_roofline_shadow(env, actions) -> dict:
+    """Per-launch times of the DirectRLEnv.step stages (hipGraph of 20 copies, HIP events) and the whole step."""
+    N = env.num_envs
+    J, Fg, A = env.num_hand_dofs, env.num_fingertips, env.cfg.action_space
+    stages = {
+        # name: (callable, algorithmic bytes per env, kernel-name fragment)
+        "apply_action": (env._apply_action, 4 * A + 20 * J, "k_inhand_apply_action"),
+        "dones": (env._get_dones, 4 * (7 + 3 + 4 + 1) + 8 + 2, "k_inhand_dones"),
+        "rewards": (env._get_rewards, 4 * (7 + 3 + 4 + A + 1) + 2 + 4 + 1, "k_inhand_rewards"),
+        "observations": (env.compute_full_observations, 4 * (2 * J + 13 + 13 * Fg + A) + 4 * env.num_full_obs,
+                         "k_inhand_full_obs"),
+    }
+    per_kernel = {}
+    for name, (fn, nbytes, frag) in stages.items():
+        dur = _graph_time(fn)
+        per_kernel[name] = {"kernel": frag, "us": 1e6 * dur, "launches_per_step": env.cfg.decimation if name == "apply_action" else 1,
+                            "alg_bytes_per_env": nbytes, "GBps": nbytes * N / dur / 1e9}
+    step_s = _graph_time(lambda: env.step(actions[0]), reps=8)
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["us"])
+    d = per_kernel[dom]
+    total = shadow_algorithmic_bytes(env)
+    return {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(d["kernel"]), "alg_bytes_per_launch": d["alg_bytes_per_env"] * N,
+            "avg_launch_us": d["us"], "alg_bytes_per_env_step": total, "whole_step_us": 1e6 * step_s,
+            "whole_step_GBps": total * N / step_s / 1e9, "kernels": per_kernel}
+
+
+def cpu_baseline_shadow(rec, args) -> dict:
+    """The numpy oracle (oracle/inhand_np.py) over the same inputs, bounded sample, one thread."""
+    from oracle import inhand_np as O
+
+    npy = lambda t: t.detach().cpu().numpy()
+    lim = npy(rec["limits"])
+    lower, upper = np.ascontiguousarray(lim[..., 0]), np.ascontiguousarray(lim[..., 1])
+    origins, goal, obj, in_hand = npy(rec["origins"]), npy(rec["goal"]), npy(rec["obj"]), npy(rec["in_hand"])
+    n, D = lower.shape
+    from isaaclab_amd.tasks.inhand import ShadowHandEnvCfg
+
+    cfg = ShadowHandEnvCfg(num_envs=n)
+    B = len(cfg.body_names)
+    rng = np.random.RandomState(0)
+    q, qd = rng.randn(n, D).astype(np.float32), rng.randn(n, D).astype(np.float32)
+    body = rng.randn(n, B, 13).astype(np.float32)
+    act_idx, fingers = np.array(rec["act_idx"]), np.array(rec["fingers"])
+    actions = npy(rec["actions"])
+    succ, cons, ep = np.zeros(n, np.float32), np.zeros(1, np.float32), np.zeros(n, np.int64)
+    cur, prev = np.zeros((n, D), np.float32), np.zeros((n, D), np.float32)
+    kw = dict(dist_reward_scale=-10.0, rot_reward_scale=1.0, rot_eps=0.1, action_penalty_scale=-0.0002,
+              success_tolerance=0.1, reach_goal_bonus=250.0, fall_dist=0.24, fall_penalty=0.0, av_factor=0.1)
+    steps = max(8, args.cpu_steps)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        a = actions[k % actions.shape[0]]
+        for _ in range(cfg.decimation):
+            cur, prev = O.apply_action(a, act_idx, lower, upper, cur, prev, cfg.act_moving_average)
+        ep = ep + 1
+        oor, to, ep = O.dones(obj, origins, in_hand, goal, succ, ep, cfg.fall_dist, cfg.success_tolerance,
+                              cfg.max_consecutive_success, 600)
+        _, _, succ, cons = O.compute_rewards(oor | to, np.zeros(n, bool), succ, cons, obj, origins, in_hand, goal, a, **kw)
+        O.full_observations(q, qd, lower, upper, obj, origins, in_hand, goal, body, fingers, a, cfg.vel_obs_scale)
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} env-steps x {n} envs of the same workload (numpy oracle, single thread), {dt:.1f} s"}
 
 
 def _graph_time(fn, reps: int = 20, replays: int = 10) -> float:

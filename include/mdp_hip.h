@@ -529,6 +529,22 @@ int mdp_math_op(int op, int64_t n,
                 const float* c, int ldc, const float* d, int ldd,
                 float* out, int ldo, int i0, float f0, void* stream);
 
+/* Samplers of LAB/utils/math.py:1250-1421 on the device generator (Philox4x32-10 keyed by {seed, epoch, kind, sample}):
+ * random_orientation :1250-1267, random_yaw_orientation :1270-1285, sample_triangle :1288-1310, sample_uniform
+ * :1313-1331, sample_log_uniform :1334-1362, sample_gaussian :1365-1384, sample_cylinder :1387-1421
+ * (default_orientation :1233-1247 is a constant fill).  `a` / `b` = per-sample lower / upper (mean / std) arrays of n
+ * floats, or NULL -> a_scalar / b_scalar; cylinder: a_scalar = radius, b_scalar..c_scalar = height range.
+ * out: n floats; (n,3) cylinder; (n,4) wxyz for the two orientation samplers.  `state` = device {seed, epoch}: the epoch
+ * is advanced on the device in stream order (a captured call keeps drawing fresh numbers).  `inject` (optional) replaces
+ * the generator: 2 uniforms per sample (the first is the standard normal for MDP_SAMPLE_GAUSSIAN), 4 standard normals
+ * per sample for MDP_SAMPLE_QUAT -- parity with the reference's transformation of a recorded draw. */
+enum {
+    MDP_SAMPLE_UNIFORM = 0, MDP_SAMPLE_LOG_UNIFORM = 1, MDP_SAMPLE_GAUSSIAN = 2, MDP_SAMPLE_TRIANGLE = 3,
+    MDP_SAMPLE_CYLINDER = 4, MDP_SAMPLE_YAW_QUAT = 5, MDP_SAMPLE_QUAT = 6, MDP_SAMPLE_NUM = 7
+};
+int mdp_sample(int kind, int64_t n, const float* a, const float* b, float a_scalar, float b_scalar, float c_scalar,
+               const float* inject, float* out, uint64_t* state, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Shadow-hand in-hand manipulation, direct workflow
  * (TASKS/direct/inhand_manipulation/inhand_manipulation_env.py:97-117,179-199,262-433)

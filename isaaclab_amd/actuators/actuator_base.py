@@ -15,8 +15,6 @@ from ..utils.types import ArticulationActions
 
 
 class ActuatorBase(ABC):
-    computed_effort: torch.Tensor
-    applied_effort: torch.Tensor
     effort_limit: torch.Tensor
     velocity_limit: torch.Tensor
     stiffness: torch.Tensor
@@ -41,6 +39,30 @@ class ActuatorBase(ABC):
         self.velocity_limit = self._parse_joint_parameter(self.cfg.velocity_limit, velocity_limit)
         self.computed_effort = torch.zeros(self._num_envs, self.num_joints, device=self._device)
         self.applied_effort = torch.zeros_like(self.computed_effort)
+
+    # A group that ``Articulation`` evaluates as part of a merged launch (``Articulation._merge_actuator_groups``) has
+    # no buffers of its own any more: its efforts are the group's columns of the merged (N, J) outputs.
+    _merged_into = None
+
+    @property
+    def computed_effort(self) -> torch.Tensor:
+        if self._merged_into is not None:
+            return self._merged_into.computed_effort[:, self._joint_indices]
+        return self._computed_effort
+
+    @computed_effort.setter
+    def computed_effort(self, value: torch.Tensor):
+        self._computed_effort = value
+
+    @property
+    def applied_effort(self) -> torch.Tensor:
+        if self._merged_into is not None:
+            return self._merged_into.applied_effort[:, self._joint_indices]
+        return self._applied_effort
+
+    @applied_effort.setter
+    def applied_effort(self, value: torch.Tensor):
+        self._applied_effort = value
 
     def __str__(self) -> str:
         joint_indices = self.joint_indices

@@ -7,7 +7,7 @@ from dataclasses import MISSING
 
 import torch
 
-from ..actuators import ActuatorBase, ImplicitActuator
+from ..actuators import ActuatorBase, DCMotor, IdealPDActuator, ImplicitActuator
 from ..utils import string as string_utils
 from ..utils.configclass import configclass
 from ..utils.types import ArticulationActions
@@ -30,7 +30,13 @@ class ArticulationCfg:
 
 
 class Articulation:
-    def __init__(self, cfg: ArticulationCfg, root_physx_view, device: str):
+    #: several stateless PD groups of one class that together cover every joint are evaluated by ONE launch over the
+    #: full (N, J) buffers (see ``_merge_actuator_groups``); ``False`` restores one launch + gather / scatter per group
+    merge_actuator_groups: bool = True
+
+    def __init__(self, cfg: ArticulationCfg, root_physx_view, device: str, merge_actuator_groups: bool | None = None):
+        if merge_actuator_groups is not None:
+            self.merge_actuator_groups = merge_actuator_groups
         self.cfg = cfg
         self.device = device
         self.root_physx_view = root_physx_view
@@ -92,13 +98,13 @@ class Articulation:
     def can_fold_joint_action(self) -> bool:
         if not getattr(self, "_single_full_group", False):
             return False
-        return bool(getattr(next(iter(self.actuators.values())), "folds_joint_action", False))
+        return bool(getattr(self._step_actuators()[0], "folds_joint_action", False))
 
     @property
     def can_carry_update(self) -> bool:
         if not getattr(self, "_single_full_group", False):
             return False
-        return bool(next(iter(self.actuators.values())).carries_scene_update)
+        return bool(self._step_actuators()[0].carries_scene_update)
 
     def update(self, dt: float):
         self._data.update(dt)
@@ -189,6 +195,65 @@ class Articulation:
                 self._single_full_group = True
                 return
         self._single_full_group = False
+        self._merged_actuator = None
+        if self.merge_actuator_groups:
+            self._merge_actuator_groups()
+
+    def _merge_actuator_groups(self):
+        """Groups of ONE stateless PD class (ImplicitActuator / IdealPDActuator / DCMotor with one saturation effort) that
+        partition the joints -- H1's legs / feet / arms (ASSETS/robots/unitree.py H1_MINIMAL_CFG) -- do the same arithmetic
+        per (env, joint) element with per-element parameters, so ``_apply_actuator_model`` (articulation.py:1399-1436)
+        runs them as one launch over the full (N, J) buffers writing ``computed_torque`` / ``applied_torque`` in place,
+        instead of a gather of five inputs, a launch and a scatter of six outputs per group.  The groups stay in
+        ``self.actuators`` with their own parameters; their ``computed_effort`` / ``applied_effort`` read through to the
+        merged buffers.  Call ``refresh_merged_actuator_parameters()`` after editing a group's gains or limits."""
+        acts = list(self.actuators.values())
+        if len(acts) < 2:
+            return
+        cls = type(acts[0])
+        if cls not in (ImplicitActuator, IdealPDActuator, DCMotor) or any(type(a) is not cls for a in acts):
+            return
+        if cls is DCMotor and len({float(a._saturation_effort) for a in acts}) != 1:
+            return
+        ids = []
+        for a in acts:
+            ji = a.joint_indices
+            ids += list(range(self.num_joints)) if ji == slice(None) else [int(i) for i in ji.tolist()]
+        if sorted(ids) != list(range(self.num_joints)):
+            return
+        n, j = self.num_instances, self.num_joints
+        merged = object.__new__(cls)
+        merged.cfg = acts[0].cfg
+        merged._num_envs, merged._device = n, self.device
+        merged._joint_names, merged._joint_indices = list(self.joint_names), slice(None)
+        for name in ("stiffness", "damping", "armature", "friction", "effort_limit", "velocity_limit"):
+            setattr(merged, name, torch.zeros((n, j), device=self.device))
+        merged.computed_effort = torch.zeros((n, j), device=self.device)
+        merged.applied_effort = torch.zeros((n, j), device=self.device)
+        if cls is DCMotor:
+            merged._saturation_effort = acts[0]._saturation_effort
+        self._merged_actuator = merged
+        self.refresh_merged_actuator_parameters()
+        d = self._data
+        d.computed_torque, d.applied_torque = merged.computed_effort, merged.applied_effort
+        d.soft_joint_vel_limits = merged.velocity_limit
+        for a in acts:
+            a._merged_into = merged
+        self._single_full_group = True
+
+    def refresh_merged_actuator_parameters(self):
+        m = self._merged_actuator
+        if m is None:
+            return
+        for a in self.actuators.values():
+            for name in ("stiffness", "damping", "armature", "friction", "effort_limit", "velocity_limit"):
+                getattr(m, name)[:, a.joint_indices] = getattr(a, name)
+
+    def _step_actuators(self) -> list:
+        """The actuator objects ``_apply_actuator_model`` evaluates: the merged one, else every group."""
+        if getattr(self, "_merged_actuator", None) is not None:
+            return [self._merged_actuator]
+        return list(self.actuators.values())
 
     def _apply_actuator_model(self, carry_update=None, joint_action=None, gate=None):
         """articulation.py:1399-1436"""
@@ -199,7 +264,7 @@ class Articulation:
             joint_vel_all = self.root_physx_view.get_dof_velocities()
         else:
             joint_pos_all, joint_vel_all = d.joint_pos, d.joint_vel
-        for actuator in self.actuators.values():
+        for actuator in self._step_actuators():
             ji = actuator.joint_indices
             actuator.pending_scene_update = carry_update
             actuator.pending_joint_action = joint_action

@@ -281,7 +281,10 @@ extern "C" int mdp_frame_transformer_update(int num_envs, int num_frames, const 
     MDP_REQUIRE((a->source_offset_pos == nullptr) == (a->source_offset_quat == nullptr), "source offset: give both or neither");
     MDP_REQUIRE((a->target_offset_pos == nullptr) == (a->target_offset_quat == nullptr), "target offset: give both or neither");
     if (num_envs <= 0 || num_frames <= 0) return MDP_OK;
-    hipLaunchKernelGGL(k_frame_transformer_update, dim3(grid_for((int64_t)num_envs * num_frames, 128)), dim3(128), 0,
+    // one thread per (env, frame) pair, no grid stride: the grid must cover every pair
+    const int64_t pairs = (int64_t)num_envs * num_frames;
+    MDP_REQUIRE(pairs <= ((int64_t)1 << 30), "%lld (env, frame) pairs exceed one launch", (long long)pairs);
+    hipLaunchKernelGGL(k_frame_transformer_update, dim3((unsigned)((pairs + 127) / 128)), dim3(128), 0,
                        as_stream(stream), num_envs, num_frames, *a);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
@@ -295,7 +298,7 @@ extern "C" int mdp_imu_update(int num_envs, const mdp_imu_args_t* a, void* strea
     MDP_REQUIRE(a->dt > 0.0f, "dt must be positive (the sensor needs one update() before its data is read)");
     MDP_REQUIRE(a->ld_coms >= 3, "coms rows must hold at least the position");
     if (num_envs <= 0) return MDP_OK;
-    hipLaunchKernelGGL(k_imu_update, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    hipLaunchKernelGGL(k_imu_update, dim3((unsigned)((num_envs + 127) / 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

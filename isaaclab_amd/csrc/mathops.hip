@@ -165,6 +165,71 @@ __global__ void k_math(int64_t n, MathArgs g) {
     }
 }
 
+// ---- samplers (math.py:1233-1421) on the counter-based generator -------------------------------------------------
+// One thread per sample.  The two uniforms of a sample come from one Philox4x32-10 block keyed by (seed, epoch, kind,
+// sample index) -- or from `inject` (2 floats per sample; 4 standard normals per sample for MDP_SAMPLE_QUAT) so the
+// reference's own transformation of a recorded torch.rand draw can be compared number for number.
+struct SampleArgs {
+    const float* a; const float* b;   // per-sample lower / upper (mean / std) or null -> the scalars
+    float as, bs, cs;                  // scalars: lower, upper (mean, std; cylinder: radius, h_min, h_max)
+    const float* inject;
+    float* out;
+    const unsigned long long* state;   // {seed, epoch}
+};
+
+template <int KIND>
+__global__ void k_sample(int64_t n, SampleArgs g) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float u1, u2, z[4];
+    if (g.inject) {
+        if (KIND == MDP_SAMPLE_QUAT) { for (int k = 0; k < 4; ++k) z[k] = g.inject[4 * i + k]; u1 = u2 = 0.0f; }
+        else { u1 = g.inject[2 * i]; u2 = g.inject[2 * i + 1]; }
+    } else {
+        const U4 r = rng4(g.state[0], g.state[1], 0x53414d50u + (uint32_t)KIND, (uint64_t)i);
+        u1 = u01(r.x); u2 = u01(r.y);
+        if (KIND == MDP_SAMPLE_QUAT) {     // two Box-Muller pairs
+            const float r1 = sqrtf(-2.0f * logf(1.0f - u1)), r2 = sqrtf(-2.0f * logf(1.0f - u01(r.z)));
+            const float t1 = 6.28318530717958647692f * u2, t2 = 6.28318530717958647692f * u01(r.w);
+            z[0] = r1 * cosf(t1); z[1] = r1 * sinf(t1); z[2] = r2 * cosf(t2); z[3] = r2 * sinf(t2);
+        }
+    }
+    const float lo = g.a ? g.a[i] : g.as, hi = g.b ? g.b[i] : g.bs;
+    if (KIND == MDP_SAMPLE_UNIFORM) {
+        g.out[i] = u1 * (hi - lo) + lo;                                  // :1331
+    } else if (KIND == MDP_SAMPLE_LOG_UNIFORM) {
+        const float ll = logf(lo), lh = logf(hi);                        // :1362
+        g.out[i] = expf(u1 * (lh - ll) + ll);
+    } else if (KIND == MDP_SAMPLE_GAUSSIAN) {
+        // torch.normal(mean, std): mean + std * z, z from Box-Muller over u1 in (0, 1]
+        const float zz = g.inject ? u1 : sqrtf(-2.0f * logf(1.0f - u1)) * cosf(6.28318530717958647692f * u2);
+        g.out[i] = lo + hi * zz;
+    } else if (KIND == MDP_SAMPLE_TRIANGLE) {
+        float r = 2.0f * u1 - 1.0f;                                      // :1304-1310
+        r = r < 0.0f ? -sqrtf(-r) : sqrtf(r);
+        r = (r + 1.0f) / 2.0f;
+        g.out[i] = (hi - lo) * r + lo;
+    } else if (KIND == MDP_SAMPLE_CYLINDER) {
+        const float ang = (u1 * 2.0f - 1.0f) * 3.14159265358979323846f;  // :1408-1419 (as = radius, bs..cs = h range)
+        g.out[3 * i + 0] = g.as * cosf(ang);
+        g.out[3 * i + 1] = g.as * sinf(ang);
+        g.out[3 * i + 2] = u2 * (g.cs - g.bs) + g.bs;
+    } else if (KIND == MDP_SAMPLE_YAW_QUAT) {
+        const float yaw = 2.0f * 3.14159265358979323846f * u1;           // :1281-1285
+        // quat_from_euler_xyz(0, 0, yaw) (math.py:251-278) with the roll / pitch factors evaluated: cos 0 = 1, sin 0 = 0
+        const float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f);
+        const float cr = 1.0f, sr = 0.0f, cp = 1.0f, sp = 0.0f;
+        st4(g.out + 4 * i, Q4{cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp,
+                              sy * cr * cp - cy * sr * sp});
+    } else if (KIND == MDP_SAMPLE_QUAT) {
+        const float nrm = sqrtf(((z[0] * z[0] + z[1] * z[1]) + z[2] * z[2]) + z[3] * z[3]);   // :1265-1267
+        const float d = tmax(nrm, 1e-12f);
+        for (int k = 0; k < 4; ++k) g.out[4 * i + k] = z[k] / d;
+    }
+}
+
+__global__ void k_sample_advance(unsigned long long* state) { state[1] += 1ull; }
+
 }  // namespace
 
 extern "C" int mdp_math_op(int op, int64_t n, const float* a, int lda, const float* b, int ldb, const float* c,
@@ -189,6 +254,29 @@ extern "C" int mdp_math_op(int op, int64_t n, const float* a, int lda, const flo
         CASE(MDP_MATH_APPLY_DELTA_POSE) CASE(MDP_MATH_SKEW) CASE(MDP_MATH_COPYSIGN)
     }
 #undef CASE
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_sample(int kind, int64_t n, const float* a, const float* b, float a_scalar, float b_scalar,
+                          float c_scalar, const float* inject, float* out, uint64_t* state, void* stream) {
+    MDP_REQUIRE(kind >= 0 && kind < MDP_SAMPLE_NUM, "unknown sampler %d", kind);
+    MDP_REQUIRE(n >= 0, "negative sample count %lld", (long long)n);
+    if (n == 0) return MDP_OK;
+    MDP_REQUIRE(out, "null output");
+    MDP_REQUIRE(inject || state, "a sampler needs its generator state {seed, epoch} (or injected numbers)");
+    MDP_REQUIRE(n <= ((int64_t)1 << 31) * 256, "sample count %lld beyond one launch", (long long)n);
+    SampleArgs g{a, b, a_scalar, b_scalar, c_scalar, inject, out, (const unsigned long long*)state};
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipStream_t s = as_stream(stream);
+#define CASE(K) case K: hipLaunchKernelGGL(k_sample<K>, grid, block, 0, s, n, g); break;
+    switch (kind) {
+        CASE(MDP_SAMPLE_UNIFORM) CASE(MDP_SAMPLE_LOG_UNIFORM) CASE(MDP_SAMPLE_GAUSSIAN) CASE(MDP_SAMPLE_TRIANGLE)
+        CASE(MDP_SAMPLE_CYLINDER) CASE(MDP_SAMPLE_YAW_QUAT) CASE(MDP_SAMPLE_QUAT)
+    }
+#undef CASE
+    // the epoch lives on the device and moves in stream order: a captured call draws fresh numbers on every replay
+    if (!inject) hipLaunchKernelGGL(k_sample_advance, dim3(1), dim3(1), 0, s, (unsigned long long*)state);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

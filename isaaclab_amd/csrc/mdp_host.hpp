@@ -42,8 +42,11 @@ inline int fail(int code, const char* fmt, ...) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// grid size for an elementwise / grid-stride kernel: enough blocks to fill 256 CUs x 8, capped.
-inline unsigned grid_for(int64_t work, int block, int64_t cap = 8192) {
+// grid size for an elementwise kernel: one thread per element up to `cap` blocks.  The default cap (2^20 blocks) is only
+// a guard for grid-stride kernels; kernels WITHOUT a grid stride (one thread per element, early return) must be
+// launched with grids that cover their work -- 2^20 blocks x 128 threads covers 134 M elements, far beyond any per-env
+// launch here; a smaller cap is passed explicitly where a kernel strides.
+inline unsigned grid_for(int64_t work, int block, int64_t cap = (int64_t)1 << 20) {
     int64_t g = (work + block - 1) / block;
     if (g < 1) g = 1;
     if (g > cap) g = cap;

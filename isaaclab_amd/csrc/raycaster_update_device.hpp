@@ -30,10 +30,15 @@ struct RaycasterUpdateArgs {
 };
 
 // height_scan observation column of ray r of env e, written by the cast kernels (mdp_height_scan_obs_t)
+// Generator stream of the height-scan noise: the per-step cast and the flagged recast after a reset read the same
+// per-block epoch words with different block -> env maps, so they draw from DIFFERENT streams -- with one stream the
+// recast of env e at epoch k would repeat, sample for sample, what the per-step cast of env e draws a few steps later.
+constexpr uint32_t SCAN_STREAM = 0x48534341u, SCAN_STREAM_FLAGGED = 0x48534346u;
+
 __device__ __forceinline__ void scan_store(const mdp_height_scan_obs_t& sc, int e, int r, int R, float sensor_z, float hit_z,
-                                           uint64_t seed, uint64_t epoch) {
+                                           uint64_t seed, uint64_t epoch, uint32_t stream = SCAN_STREAM) {
     float v = (sensor_z - hit_z) - sc.offset;   // observations.py:173
-    v = obs_post(sc.post, v, e, r, seed, epoch, 0x48534341u, (uint64_t)e * (uint64_t)R + (uint64_t)r);
+    v = obs_post(sc.post, v, e, r, seed, epoch, stream, (uint64_t)e * (uint64_t)R + (uint64_t)r);
     sc.obs[(int64_t)e * sc.ld_obs + sc.col_offset + r] = v;
     if (sc.normalize.out) {      // the standardised copy for the observation's consumer (mdp_obs_normalize_t)
         const int c = sc.col_offset + r;
@@ -54,7 +59,7 @@ constexpr int RCU_MAX_EPB = 256;   // blockDim.x <= 1024 and num_rays >= 1; call
 // ray r of env e: start rotated by the yaw quaternion, one grid-cell walk, hit point and height_scan column stored
 template <int BATCH>
 __device__ __forceinline__ void raycaster_down_ray(const RaycasterUpdateArgs& a, int e, int r, V3 pos, Q4 qr, uint64_t seed,
-                                                   uint64_t epoch) {
+                                                   uint64_t epoch, uint32_t stream = SCAN_STREAM) {
     const mdp_mesh_view_t& mesh = a.mesh;
     const int R = a.R;
     const float inf = __builtin_inff();
@@ -84,7 +89,7 @@ __device__ __forceinline__ void raycaster_down_ray(const RaycasterUpdateArgs& a,
     } else {
         o[0] = inf; o[1] = inf; o[2] = inf;
     }
-    if (a.scan.obs) scan_store(a.scan, e, r, R, pos.z, hz, seed, epoch);
+    if (a.scan.obs) scan_store(a.scan, e, r, R, pos.z, hz, seed, epoch, stream);
 }
 
 template <int BATCH>
@@ -207,7 +212,8 @@ __device__ __forceinline__ void raycaster_update_flagged_blocks(const RaycasterU
         any = true;
         const V3 pos = V3{se[0], se[1], se[2]};
         const Q4 qr = Q4{se[3], 0.0f, 0.0f, se[4]};
-        for (int r = threadIdx.x; r < R; r += blockDim.x) raycaster_down_ray<BATCH>(a, base + le, r, pos, qr, seed, epoch);
+        for (int r = threadIdx.x; r < R; r += blockDim.x)
+            raycaster_down_ray<BATCH>(a, base + le, r, pos, qr, seed, epoch, SCAN_STREAM_FLAGGED);
     }
     if (any && scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
 }

@@ -184,7 +184,9 @@ __global__ void k_scaler_update(int P, int D, const double* __restrict__ partial
             n = tot;
         }
         if (n > 0.0) {
-            const double var_b = m2 / (n > 1.0 ? n - 1.0 : 1.0);
+            // torch.var (Bessel): a single-row batch gives 0 / 0 = NaN, which the reference lets into its running variance
+            // (my_running_standard_scaler.py:74-80); reproduced, not repaired
+            const double var_b = m2 / (n - 1.0);
             const double delta = mean - running_mean[c];
             const double tot = cur + n;
             const double M2 = running_var[c] * cur + var_b * n + delta * delta * cur * n / tot;

@@ -176,7 +176,10 @@ class ObservationManager(ManagerBase):
                 fill_noise(t, cfg.noise)
                 injected = getattr(cfg, "_injected_noise", None)
                 if injected is not None:
-                    t.noise_u = L.f32(injected).contiguous().data_ptr()
+                    if injected.dtype != torch.float32 or not injected.is_contiguous():
+                        raise ValueError("injected observation noise must be a contiguous float32 tensor (the term table"
+                                         " keeps its address)")
+                    t.noise_u = L.require_gpu(injected, "injected noise").data_ptr()
                     self._keepalive.append(injected)
             if cfg.clip:
                 t.has_clip, t.clip_lo, t.clip_hi = 1, float(cfg.clip[0]), float(cfg.clip[1])

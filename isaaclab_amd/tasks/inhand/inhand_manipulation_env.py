@@ -46,7 +46,11 @@ class _Hand:
         self.joint_pos_target = torch.zeros(view.count, self.num_joints, device=device)
 
     def set_joint_position_target(self, target: torch.Tensor, joint_ids=None, env_ids=None):
-        """articulation.py:807-830"""
+        """articulation.py:807-830 (``joint_ids`` as a device index tensor keeps the call free of host-to-device
+        copies, i.e. capturable in a hipGraph)"""
+        if env_ids is None and isinstance(joint_ids, torch.Tensor):
+            self.joint_pos_target.index_copy_(1, joint_ids, target)
+            return
         rows = slice(None) if env_ids is None else env_ids
         cols = slice(None) if joint_ids is None else joint_ids
         self.joint_pos_target[rows, cols] = target
@@ -149,8 +153,16 @@ class InHandManipulationEnv:
         L.check(L.lib.mdp_inhand_apply_action(C.byref(self._ccfg), L.ptr(self.actions), L.ptr(self._act_idx),
                                               L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
                                               L.ptr(self.cur_targets), L.ptr(self.prev_targets), L.stream()))
-        self.hand.set_joint_position_target(self.cur_targets[:, self.actuated_dof_indices],
-                                            joint_ids=self.actuated_dof_indices)
+        idx = self._act_idx_long()
+        self.hand.set_joint_position_target(self.cur_targets.index_select(1, idx), joint_ids=idx)
+
+    def _act_idx_long(self) -> torch.Tensor:
+        """``actuated_dof_indices`` as a device int64 tensor (rebuilt when ``_act_idx`` is replaced)."""
+        cached = getattr(self, "_act_idx_cache", None)
+        if cached is None or cached[0] is not self._act_idx:
+            cached = (self._act_idx, self._act_idx.to(torch.long))
+            self._act_idx_cache = cached
+        return cached[1]
 
     def _get_dones(self) -> tuple[torch.Tensor, torch.Tensor]:
         """:179-199 (``_compute_intermediate_values`` is folded into the kernels: they read the raw state)."""

@@ -300,65 +300,112 @@ def transform_points(points: torch.Tensor, pos: torch.Tensor | None = None, quat
     return out if is_batched else out.squeeze(0)
 
 
-# -- samplers (math.py:1233-1421): RNG-consuming, distribution parity only ------------------------
-
-def sample_triangle(lower: float, upper: float, size, device) -> torch.Tensor:
-    """math.py:1287-1310: triangular law on [lower, upper] from one uniform draw of the torch generator (reset-time
-    sampler: it consumes the global generator exactly like the reference, so it stays a torch op)."""
-    if isinstance(size, int):
-        size = (size,)
-    u = 2.0 * torch.rand(*size, device=device) - 1.0
-    tri = torch.sign(u) * torch.sqrt(torch.abs(u))
-    return (upper - lower) * ((tri + 1.0) / 2.0) + lower
+# -- samplers (math.py:1233-1421) on the device generator (``mdp_sample``) ----------------------------------------
+# The reference draws from torch's global generator; streams cannot be matched number for number, so parity is the
+# transformation of a given draw (``_inject``: tests/test_gpu_samplers.py against vectors the reference functions
+# produced from recorded draws) plus ranges and moments.  Generator state {seed, epoch} lives on the device, one pair
+# per device, seeded from ``torch.initial_seed()`` on first use (``seed_samplers`` re-seeds); the epoch advances on the
+# device in stream order, so a call captured in a hipGraph keeps drawing fresh numbers.
+_SAMPLE_KINDS = L._parse_enum(L._HDR, "MDP_SAMPLE_")
+_sampler_state: dict[int, torch.Tensor] = {}
 
 
-def sample_cylinder(radius: float, h_range, size, device) -> torch.Tensor:
-    """math.py:1384-1421: points on the lateral surface of a z-aligned cylinder; angle first, then height, in the
-    reference's draw order."""
-    shape = (size,) if isinstance(size, int) else tuple(size)
-    angles = (torch.rand(shape, device=device) * 2.0 - 1.0) * math.pi
-    xyz = torch.zeros(shape + (3,), device=device)
-    xyz[..., 0] = radius * torch.cos(angles)
-    xyz[..., 1] = radius * torch.sin(angles)
-    xyz[..., 2].uniform_(h_range[0], h_range[1])
-    return xyz
+def seed_samplers(seed: int, device="cuda:0") -> None:
+    dev = torch.device(device)
+    _sampler_state[L.device_index(dev)] = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
 
 
-def sample_uniform(lower, upper, size, device) -> torch.Tensor:
-    if isinstance(size, int):
-        size = (size,)
-    return torch.rand(*size, device=device) * (upper - lower) + lower
+def _state(device) -> torch.Tensor:
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise ValueError(f"samplers run on the HIP device generator; got device '{device}' (there is no CPU path)")
+    idx = L.device_index(dev)
+    if idx not in _sampler_state:
+        seed_samplers(torch.initial_seed(), dev)
+    return _sampler_state[idx]
 
 
-def sample_log_uniform(lower, upper, size, device) -> torch.Tensor:
-    if not isinstance(lower, torch.Tensor):
-        lower = torch.tensor(lower, dtype=torch.float, device=device)
-    if not isinstance(upper, torch.Tensor):
-        upper = torch.tensor(upper, dtype=torch.float, device=device)
-    return torch.exp(sample_uniform(torch.log(lower), torch.log(upper), size, device))
+def _sample(kind: str, shape: tuple, device, a=None, b=None, scalars=(0.0, 0.0, 0.0), width: int = 1,
+            _inject: torch.Tensor | None = None) -> torch.Tensor:
+    n = 1
+    for d_ in shape:
+        n *= int(d_)
+    out = torch.empty(tuple(shape) + ((width,) if width > 1 else ()), dtype=torch.float32, device=device)
+    arrs = []
+    for t in (a, b):
+        if t is None:
+            arrs.append(None)
+        else:
+            arrs.append(L.f32(t.to(device), "bound").expand(shape).contiguous())
+    inj = None if _inject is None else L.f32(_inject, "injected numbers").contiguous()
+    if inj is not None and inj.numel() != n * (4 if kind == "MDP_SAMPLE_QUAT" else 2):
+        raise ValueError(f"injected numbers: expected {n * (4 if kind == 'MDP_SAMPLE_QUAT' else 2)} values, got {inj.numel()}")
+    state = None if inj is not None else _state(device)
+    L.check(L.lib.mdp_sample(_SAMPLE_KINDS[kind], n, L.ptr(arrs[0]), L.ptr(arrs[1]), float(scalars[0]), float(scalars[1]),
+                             float(scalars[2]), L.ptr(inj), out.data_ptr(), L.ptr(state), L.stream(out.device)))
+    return out
 
 
-def sample_gaussian(mean, std, size, device) -> torch.Tensor:
+def _size(size) -> tuple:
+    return (size,) if isinstance(size, int) else tuple(size)
+
+
+def _bounds(lower, upper, device):
+    """(a, b, scalars) of ``_sample``: tensors stay per-element arrays, numbers become kernel scalars."""
+    ta = lower if isinstance(lower, torch.Tensor) else None
+    tb = upper if isinstance(upper, torch.Tensor) else None
+    if (ta is None) != (tb is None):       # mixed: promote the number
+        if ta is None:
+            ta = torch.full_like(tb, float(lower))
+        else:
+            tb = torch.full_like(ta, float(upper))
+    sc = (0.0 if ta is not None else float(lower), 0.0 if tb is not None else float(upper), 0.0)
+    return ta, tb, sc
+
+
+def sample_triangle(lower: float, upper: float, size, device, _inject=None) -> torch.Tensor:
+    """math.py:1288-1310"""
+    return _sample("MDP_SAMPLE_TRIANGLE", _size(size), device, scalars=(lower, upper, 0.0), _inject=_inject)
+
+
+def sample_uniform(lower, upper, size, device, _inject=None) -> torch.Tensor:
+    """math.py:1313-1331"""
+    a, b, sc = _bounds(lower, upper, device)
+    return _sample("MDP_SAMPLE_UNIFORM", _size(size), device, a, b, sc, _inject=_inject)
+
+
+def sample_log_uniform(lower, upper, size, device, _inject=None) -> torch.Tensor:
+    """math.py:1334-1362 (log of the bounds, uniform draw and exp all inside the launch)"""
+    a, b, sc = _bounds(lower, upper, device)
+    return _sample("MDP_SAMPLE_LOG_UNIFORM", _size(size), device, a, b, sc, _inject=_inject)
+
+
+def sample_gaussian(mean, std, size, device, _inject=None) -> torch.Tensor:
+    """math.py:1365-1384: float mean -> ``size`` samples; tensor mean -> one sample per element of ``mean``."""
     if isinstance(mean, float):
-        if isinstance(size, int):
-            size = (size,)
-        return torch.normal(mean=mean, std=std, size=size).to(device=device)
-    return torch.normal(mean=mean, std=std).to(device=device)
+        return _sample("MDP_SAMPLE_GAUSSIAN", _size(size), device, scalars=(mean, float(std), 0.0), _inject=_inject)
+    std_t = std if isinstance(std, torch.Tensor) else torch.full_like(mean, float(std))
+    return _sample("MDP_SAMPLE_GAUSSIAN", tuple(mean.shape), device, mean, std_t, _inject=_inject)
+
+
+def sample_cylinder(radius: float, h_range, size, device, _inject=None) -> torch.Tensor:
+    """math.py:1387-1421: points on the lateral surface of a z-aligned cylinder, shape (*size, 3)."""
+    return _sample("MDP_SAMPLE_CYLINDER", _size(size), device, scalars=(radius, h_range[0], h_range[1]), width=3,
+                   _inject=_inject)
 
 
 def default_orientation(num: int, device: str) -> torch.Tensor:
+    """math.py:1233-1247 (a constant: one fill)"""
     quat = torch.zeros((num, 4), dtype=torch.float, device=device)
     quat[..., 0] = 1.0
     return quat
 
 
-def random_yaw_orientation(num: int, device: str) -> torch.Tensor:
-    roll = torch.zeros(num, dtype=torch.float, device=device)
-    pitch = torch.zeros(num, dtype=torch.float, device=device)
-    yaw = 2 * math.pi * torch.rand(num, dtype=torch.float, device=device)
-    return quat_from_euler_xyz(roll, pitch, yaw)
+def random_yaw_orientation(num: int, device: str, _inject=None) -> torch.Tensor:
+    """math.py:1270-1285"""
+    return _sample("MDP_SAMPLE_YAW_QUAT", (num,), device, width=4, _inject=_inject)
 
 
-def random_orientation(num: int, device: str) -> torch.Tensor:
-    quat = torch.randn((num, 4), dtype=torch.float, device=device)
-    return normalize(quat)
+def random_orientation(num: int, device: str, _inject=None) -> torch.Tensor:
+    """math.py:1250-1267"""
+    return _sample("MDP_SAMPLE_QUAT", (num,), device, width=4, _inject=_inject)

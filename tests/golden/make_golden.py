@@ -1247,11 +1247,57 @@ def gen_terrains():
     save("terrains", **out)
 
 
+def gen_samplers():
+    """Samplers of utils/math.py:1233-1421 run by the REFERENCE functions on recorded draws: torch.rand / torch.randn
+    hand out prepared tensors while they run (for the scripted ones the module is loaded a second time with
+    torch.jit.script as the identity, so the same Python bodies run eagerly).  Two draws have no torch.rand call to
+    intercept and are fed the recorded numbers through their documented transformation: Tensor.uniform_(a, b) =
+    a + (b - a) * u and torch.normal(mean, std) = mean + std * z."""
+    script = torch.jit.script
+    torch.jit.script = lambda f, *a, **k: f
+    try:
+        m = R.load_by_path("_ref_math_eager", os.path.join(R.LAB, "isaaclab", "utils", "math.py"))
+    finally:
+        torch.jit.script = script
+    g = torch.Generator().manual_seed(1212)
+    n = 257
+    u = torch.rand(n, 2, generator=g)
+    u[0, 0], u[1, 0], u[2, 0] = 0.0, 0.5, 1.0 - 2.0 ** -24
+    z = torch.randn(n, 4, generator=g)
+    out = {"u": u, "z": z}
+    with _RandQueue(rand=[u[:, 0]]):
+        out["uniform"] = m.sample_uniform(-0.7, 2.5, n, "cpu")
+    lo = torch.rand(n, generator=g) - 1.5
+    hi = lo + 0.1 + torch.rand(n, generator=g) * 3.0
+    out["lo"], out["hi"] = lo, hi
+    with _RandQueue(rand=[u[:, 0]]):
+        out["uniform_tensor"] = m.sample_uniform(lo, hi, (n,), "cpu")
+    with _RandQueue(rand=[u[:, 0]]):
+        out["log_uniform"] = m.sample_log_uniform(1e-3, 10.0, n, "cpu")
+    with _RandQueue(rand=[u[:, 0]]):
+        out["triangle"] = m.sample_triangle(-1.0, 3.0, (n,), "cpu")
+    with _RandQueue(rand=[u[:, 0]]):
+        out["yaw_quat"] = m.random_yaw_orientation(n, "cpu")
+    randn, normal, uniform_ = torch.randn, torch.normal, torch.Tensor.uniform_
+    try:
+        torch.randn = lambda *a, **k: z.clone()
+        out["quat"] = m.random_orientation(n, "cpu")
+        torch.normal = lambda mean, std, size=None, **k: mean + std * (z[:, 0] if size is None else z[:, 0].reshape(size))
+        out["gaussian"] = m.sample_gaussian(0.3, 1.7, (n,), "cpu")
+        out["gaussian_tensor"] = m.sample_gaussian(lo, hi - lo, (n,), "cpu")
+        torch.Tensor.uniform_ = lambda self, a=0.0, b=1.0: self.copy_(a + (b - a) * u[:, 1].reshape(self.shape))
+        with _RandQueue(rand=[u[:, 0]]):
+            out["cylinder"] = m.sample_cylinder(0.35, (-0.2, 0.9), n, "cpu")
+    finally:
+        torch.randn, torch.normal, torch.Tensor.uniform_ = randn, normal, uniform_
+    save("samplers", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera", "samplers"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
              "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
              "events": gen_events, "terrains": gen_terrains, "imu": gen_imu,
-             "frames": gen_frame_transformer, "camera": gen_camera}
+             "frames": gen_frame_transformer, "camera": gen_camera, "samplers": gen_samplers}
     for w in which:
         table[w]()

@@ -123,18 +123,29 @@ def test_anymal_c_rough_lstm(device):
     assert act.sea_hidden_state.abs().max().item() > 0.0
 
 
-@pytest.mark.parametrize("n,fused", ((48, True), (19, False)))
-def test_h1_rough(device, n, fused):
+@pytest.mark.parametrize("n,fused,merged", ((48, True, True), (19, False, True), (33, True, False)))
+def test_h1_rough(device, n, fused, merged, monkeypatch):
     """BASELINE config C4 shape (Isaac-Velocity-Rough-H1-v0: 19 joints in three implicit-actuator groups addressed by
-    index lists, 20 bodies, biped reward terms incl. feet_slide on body velocities, 256-dim observation)."""
+    index lists, 20 bodies, biped reward terms incl. feet_slide on body velocities, 256-dim observation).  The three
+    groups run as ONE launch over the full (N, J) buffers (Articulation.merge_actuator_groups, the default) or as one
+    launch + gathers / scatters per group; the groups' own efforts read through to the merged buffers."""
+    from isaaclab_amd.assets.articulation import Articulation
     from oracle.harness import build_oracle, replay_oracle
 
+    monkeypatch.setattr(Articulation, "merge_actuator_groups", merged)
     env, rec, outs = run_env("h1_rough", n, 5, device, seed=15, small_terrain=True, fused=fused)
     assert outs[0][0].shape == (n, 256)
     orc = build_oracle(rec)
     assert env.reward_manager.active_terms == [name for name, _, _ in orc.s["rewards"]]
-    assert len(env.scene["robot"].actuators) == 3
+    robot = env.scene["robot"]
+    assert len(robot.actuators) == 3
+    assert (robot._merged_actuator is not None) == merged
     compare(outs, replay_oracle(rec, 5))
+    for act in robot.actuators.values():
+        ji = act.joint_indices
+        np.testing.assert_array_equal(to_np(act.applied_effort), to_np(robot.data.applied_torque[:, ji]))
+        np.testing.assert_array_equal(to_np(act.computed_effort), to_np(robot.data.computed_torque[:, ji]))
+    assert float(robot.data.computed_torque.abs().max()) > 0.0
 
 
 def test_post_physics_step_rejects_what_it_does_not_cover(device):
@@ -267,6 +278,50 @@ def test_raycaster_update_flagged(device):
     a, b = got[touched], sensor.data.ray_hits_w[touched]
     assert torch.equal(torch.nan_to_num(a, posinf=1e30), torch.nan_to_num(b, posinf=1e30))
     assert not torch.equal(sensor.data.ray_hits_w[~touched], hits0[~touched])
+
+
+def test_flagged_recast_draws_its_own_noise(device):
+    """The recast of the reset envs and the per-step cast read the same per-block epoch words; on ONE generator stream the
+    noise a reset env got in its recast came back sample for sample in its next per-step cast.  Static pose, device
+    generator on: the height-scan columns written by the recast must differ from those of the next step's cast (and
+    two per-step casts from each other)."""
+    import ctypes as C
+
+    import torch
+
+    from isaaclab_amd import _lib as L
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+
+    n = 48
+    env, rec = make_velocity_env("anymal_d_rough", num_envs=n, device=str(device), steps=2, seed=29, small_terrain=True,
+                                 inject_random=False, mesh_accel="grid")
+    env.observation_manager.persistent_output = True
+    env.step(rec.actions[0].to(device))
+    env.step(rec.actions[1].to(device))
+    oa = env.observation_manager.post_physics_args()
+    assert oa is not None
+    _, sensor, scan, _, _, out = oa
+    lo, R = scan.col_offset, sensor.num_rays
+    cols = lambda: out[:, lo:lo + R].clone()
+
+    def cast():
+        sensor._is_outdated.fill_(True)
+        sensor._update_outdated_buffers(scan=scan, from_physics=True)
+        return cols()
+
+    a = cast()
+    mask = torch.ones(n, dtype=torch.uint8, device=device)
+    args = sensor.fill_post_physics(scan, 0.0)
+    L.check(L.lib.mdp_raycaster_update_flagged(n, C.byref(args), mask.data_ptr(), L.stream(device)))
+    f = cols()
+    b = cast()
+    c = cast()
+    torch.cuda.synchronize()
+    free = (a.abs() < 0.99) & (f.abs() < 0.99) & (b.abs() < 0.99) & (c.abs() < 0.99)   # not pinned by the clip
+    assert free.float().mean() > 0.5
+    for x, y in ((f, b), (f, c), (f, a), (a, b), (b, c)):
+        assert ((x != y) & free).sum() > 0.98 * free.sum()
+        assert (x - y)[free].abs().max() <= 0.2 + 1e-6          # same hits, noise of +-0.1 each
 
 
 @pytest.mark.parametrize("name,mode", (("anymal_d_flat", True), ("anymal_d_flat", "masked"),
