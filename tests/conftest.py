@@ -43,10 +43,34 @@ def golden():
     return get
 
 
+def _record(a, e, rtol, atol, msg):
+    """MDP_PARITY_TABLE=<file>: one line per floating-point comparison -- worst absolute error, the value it occurred
+    at, its size in units in the last place of that value, worst relative error and the absolute floor the comparison
+    would need at rtol = 1e-5 (<= 0: none).  profiles/r02_parity_error_table.txt is such a run on the MI355X."""
+    path = os.environ.get("MDP_PARITY_TABLE")
+    if not path or a.size == 0:
+        return
+    a64, e64 = a.astype(np.float64), e.astype(np.float64)
+    fin = np.isfinite(a64) & np.isfinite(e64)
+    if not fin.any():
+        return
+    d = np.where(fin, np.abs(a64 - e64), 0.0)
+    i = np.unravel_index(d.argmax(), d.shape)
+    ulp = np.spacing(np.abs(e[i]).astype(np.float32)) if e.dtype == np.float32 else np.spacing(np.float32(abs(e64[i])))
+    rel = np.where(fin & (e64 != 0), d / np.maximum(np.abs(e64), 1e-300), 0.0)
+    need = float(np.max(np.where(fin, d - RTOL * np.abs(e64), -np.inf)))
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    with open(path, "a") as f:
+        f.write(f"{test}\t{msg}\tmax_abs={d.max():.3e}\tat={e64[i]:.5g}\tulps={d.max() / float(ulp):.1f}"
+                f"\tmax_rel={rel.max():.3e}\tatol_needed_at_rtol_1e-5={need:.3e}\tused_rtol={rtol:g}\tused_atol={atol:g}\n")
+
+
 def assert_close(actual, expected, rtol=RTOL, atol=ATOL, msg=""):
     a = np.asarray(actual)
     e = np.asarray(expected)
     assert a.shape == e.shape, f"{msg}: shape {a.shape} vs {e.shape}"
+    if not (e.dtype == np.bool_ or np.issubdtype(e.dtype, np.integer)):
+        _record(a, e, rtol, atol, msg)
     if e.dtype == np.bool_ or np.issubdtype(e.dtype, np.integer):
         np.testing.assert_array_equal(a, e, err_msg=msg)
     else:

@@ -1,11 +1,12 @@
 """GPU: ``isaaclab_amd.utils.math`` (HIP, through ``mdp_math_op`` of the C ABI) against the reference-generated
-fixtures and the numpy oracle.  Tolerance: fp32 <= 1e-5 relative (2e-5 where acos/atan2 chains amplify ulps,
-same as the oracle-vs-reference check), sign selections bit-exact via the values themselves."""
+fixtures and the numpy oracle.  Tolerance: fp32 <= 1e-5 relative with the 2e-6 absolute floor of conftest.py (8 ulp of
+pi, for angles that cancel to ~0; measured worst cases in profiles/r02_parity_error_table.txt), sign selections
+bit-exact via the values themselves."""
 import numpy as np
 import pytest
 
 from conftest import assert_close, to_np
-from test_oracle_math import LOOSE, SIZES, math_cases
+from test_oracle_math import SIZES, math_cases
 
 pytestmark = pytest.mark.gpu
 
@@ -40,8 +41,7 @@ def test_math_vs_reference_fixtures(golden, device, n):
     G = golden("math")
     dm = DeviceMath(device)
     for name, fn in math_cases(G, n):
-        tol = LOOSE.get(name, 1e-5)
-        assert_close(fn(dm), G[f"n{n}_{name}"], rtol=tol, atol=tol, msg=f"{name} n={n}")
+        assert_close(fn(dm), G[f"n{n}_{name}"], rtol=1e-5, atol=2e-6, msg=f"{name} n={n}")
 
 
 def test_transform_points(golden, device):
@@ -50,7 +50,7 @@ def test_transform_points(golden, device):
     for n in SIZES:
         p = f"n{n}_"
         assert_close(dm.transform_points(G[p + "pts"], G[p + "t1"], G[p + "q1"]), G[p + "transform_points"],
-                     rtol=1e-5, atol=1e-5)
+                     rtol=1e-5, atol=2e-6, msg=f"transform_points n={n}")
 
 
 def test_math_vs_oracle_large(device):
@@ -69,7 +69,7 @@ def test_math_vs_oracle_large(device):
     assert_close(dm.yaw_quat(q), M.yaw_quat(q), rtol=1e-5, atol=2e-6)
     assert_close(dm.quat_apply_yaw(q, v), M.quat_apply_yaw(q, v), rtol=1e-5, atol=4e-6)
     ang = (rng.random((n,)).astype(np.float32) - 0.5) * 100
-    assert_close(dm.wrap_to_pi(ang), M.wrap_to_pi(ang), rtol=1e-5, atol=1e-5)
+    assert_close(dm.wrap_to_pi(ang), M.wrap_to_pi(ang), rtol=1e-5, atol=4e-6, msg="wrap_to_pi |x| <= 50 (ulp of 50 = 3.8e-6)")
     # size-independent properties: rotate o rotate_inverse = id, |q1*q2| = 1
     back = dm.quat_rotate(q, dm.quat_rotate_inverse(q, v))
     assert_close(back, v, rtol=1e-5, atol=4e-6)
