@@ -510,6 +510,38 @@ def _pmc_traffic(kernel_fragment: str):
     return None
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32, dense (MI355X_MICROARCH.md: equals the f32 vector peak)
+
+
+def _mfma_summary(env, per_kernel) -> dict | None:
+    """MFMA figures of the actuator-net launch (north_star: "MFMA utilisation for the actuator nets").  Instruction
+    count and flop are exact properties of the kernel (one v_mfma_f32_16x16x4_f32 = 2048 flop per (env, joint) row per
+    launch: 16 per 16-row wave, checked against SQ_INSTS_MFMA / SQ_INSTS_VALU_MFMA_MOPS_F32 of the committed counter
+    pass); the rate uses the launch time measured live above.  `util_pmc` is rocprofv3's MfmaUtil definition,
+    SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs), from profiles/pmc_mfma.json (own --pmc pass, C3 size)."""
+    robot = env.scene["robot"]
+    if not any(hasattr(a, "sea_hidden_state") for a in robot.actuators.values()):
+        return None
+    key = "actuator+scene_update" if "actuator+scene_update" in per_kernel else "actuator"
+    if key not in per_kernel:
+        return None
+    rows = env.num_envs * robot.num_joints
+    flops = 2048.0 * rows
+    dur = per_kernel[key]["us"] * 1e-6
+    out = {"kernel": "k_lstm8_reg", "stage": key, "mfma_insts_per_launch": rows, "flop_per_launch": flops,
+           "achieved": flops / dur / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": flops / dur / 1e12 / MFMA_F32_PEAK_TFLOPS, "busy_cycles_per_launch": 32.0 * rows,
+           "bound": "hbm (6 flop per algorithmic byte: the (h, c) state round-trips every sub-step)"}
+    path = os.path.join(ROOT, "profiles", "pmc_mfma.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            pmc = json.load(f)
+        out["util_pmc"] = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (pmc["GRBM_GUI_ACTIVE_sum_over_8_xcds"] / 8.0 * pmc["simds"])
+        out["util_pmc_envs"] = pmc["envs"]
+        out["pmc_insts_per_row"] = pmc["SQ_INSTS_MFMA"] / pmc["rows"]
+    return out
+
+
 def measure_roofline(env, args) -> dict:
     """Times every launch of the step in isolation and reports the one with the largest share of the step."""
     table = algorithmic_bytes(env)
@@ -542,7 +574,11 @@ def measure_roofline(env, args) -> dict:
             per_kernel[name] = {"kernel": frag, "us": 1e6 * dur, "launches_per_step": launches,
                                 "alg_bytes_per_env": nbytes, "GBps": nbytes * N / dur / 1e9}
         hs.cfg.update_period = period
-        return _roofline_summary(table, per_kernel, N)
+        roof = _roofline_summary(table, per_kernel, N)
+        mfma = _mfma_summary(env, per_kernel)
+        if mfma is not None:
+            roof["mfma"] = mfma
+        return roof
     fns = {
         "actuator": lambda: robot.write_data_to_sim(),
         "scene_update": lambda: env.scene.update(env.physics_dt),

@@ -62,7 +62,8 @@ typedef struct {
 } mdp_hit_t;
 
 // Top bit of a cell_start entry's first word (the low 31 bits are the list offset): the triangles of the
-// cell have pairwise disjoint xy interiors and none projects to a segment.  A VERTICAL ray strictly inside one
+// cell have pairwise disjoint xy interiors; a triangle that projects to a segment (vertical wall) stays out of every
+// open interior.  A VERTICAL ray strictly inside one
 // footprint of such a cell cannot touch any other triangle of the cell, so its walk ends there whatever the record
 // order; the records of such a cell are ordered by coverage of the cell, NOT by zmax, so the zmax early exit must not
 // be used in it (a per-record skip is still valid).
@@ -428,22 +429,32 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down(const mdp_mesh_view_t* m, 
 // opposite signs) the neighbour rejects it too: the closest hit over all triangles is this one, same t bit for bit.
 // Everything else -- unsafe square, a zero edge function, a point outside both footprints (vertices moved by the
 // slope correction), a ray outside every patch -- returns 0 and the caller walks the grid cell as before.
-__device__ __forceinline__ int mdp_rc_patch_down(const mdp_mesh_view_t* m, float ox, float oy, float oz, float dz,
-                                                 float max_t, mdp_hit_t* out) {
+// The three steps of mdp_rc_patch_down as separate routines (the wave-per-env cast issues the loads of several rays
+// between them): coarse cell of the ray -> lattice square from the cell's entry -> test of the square's two triangles.
+__device__ __forceinline__ bool mdp_rc_patch_cell(const mdp_mesh_view_t* m, float ox, float oy, int* pcell) {
     const int pcx = (int)floorf((ox - m->pgx0) * m->pg_inv);
     const int pcy = (int)floorf((oy - m->pgy0) * m->pg_inv);
-    if (pcx < 0 || pcx >= m->pgnx || pcy < 0 || pcy >= m->pgny) return 0;
-    const int4* pc = reinterpret_cast<const int4*>(m->patch_cells) + 2 * (pcy * m->pgnx + pcx);
-    const int4 c0 = pc[0], c1 = pc[1];
+    if (pcx < 0 || pcx >= m->pgnx || pcy < 0 || pcy >= m->pgny) return false;
+    *pcell = pcy * m->pgnx + pcx;
+    return true;
+}
+
+// c0, c1 = the coarse cell's two words-of-four; false: no patch here / the ray is outside the patch's lattice
+__device__ __forceinline__ bool mdp_rc_patch_square(int4 c0, int4 c1, float ox, float oy, int* vidx, int* ncols_out) {
     const int voff = c0.w;
-    if (voff < 0) return 0;
+    if (voff < 0) return false;
     const int ncols = c1.x, ni = c1.y, nj = c1.z, swap = c1.w;
     const float o_i = __int_as_float(c0.x), o_j = __int_as_float(c0.y), inv_h = __int_as_float(c0.z);
     const int i = (int)floorf(((swap ? oy : ox) - o_i) * inv_h);
     const int j = (int)floorf(((swap ? ox : oy) - o_j) * inv_h);
-    if (i < 0 || i >= ni || j < 0 || j >= nj) return 0;
-    const float4* V = reinterpret_cast<const float4*>(m->patch_verts) + (voff + i * ncols + j);
-    const float4 v00 = V[0], v01 = V[1], v10 = V[ncols], v11 = V[ncols + 1];
+    if (i < 0 || i >= ni || j < 0 || j >= nj) return false;
+    *vidx = voff + i * ncols + j;
+    *ncols_out = ncols;
+    return true;
+}
+
+__device__ __forceinline__ int mdp_rc_patch_eval(float4 v00, float4 v01, float4 v10, float4 v11, float ox, float oy,
+                                                 float oz, float dz, float max_t, mdp_hit_t* out) {
     if (!(__float_as_int(v00.w) & 1)) return 0;
     const float Sz = 1.0f / dz;
     // face 2k = (v00, v11, v01), face 2k + 1 = (v00, v10, v11); edge functions as in mdp_rc_grid_down_exact
@@ -472,6 +483,18 @@ __device__ __forceinline__ int mdp_rc_patch_down(const mdp_mesh_view_t* m, float
     return 0;
 }
 
+__device__ __forceinline__ int mdp_rc_patch_down(const mdp_mesh_view_t* m, float ox, float oy, float oz, float dz,
+                                                 float max_t, mdp_hit_t* out) {
+    int pcell;
+    if (!mdp_rc_patch_cell(m, ox, oy, &pcell)) return 0;
+    const int4* pc = reinterpret_cast<const int4*>(m->patch_cells) + 2 * pcell;
+    const int4 c0 = pc[0], c1 = pc[1];
+    int vidx, ncols;
+    if (!mdp_rc_patch_square(c0, c1, ox, oy, &vidx, &ncols)) return 0;
+    const float4* V = reinterpret_cast<const float4*>(m->patch_verts) + vidx;
+    return mdp_rc_patch_eval(V[0], V[1], V[ncols], V[ncols + 1], ox, oy, oz, dz, max_t, out);
+}
+
 // mdp_rc_grid_down for an EXACTLY vertical ray (d.x == d.y == 0, d.z < 0) on a mesh with finite vertices, with the
 // arithmetic that cannot change a result removed (the cast kernel is bound by vector instructions, not by memory):
 //   * Sx = d.y / d.z and Sy = d.x / d.z are zeros, so Sx * Az3 is a zero and Ax = Ay3 - Sx * Az3 == Ay3 bit for bit for
@@ -479,19 +502,72 @@ __device__ __forceinline__ int mdp_rc_patch_down(const mdp_mesh_view_t* m, float
 //     term or comparison against 0 can see);
 //   * the z-slab clip only prunes: a triangle hit needs 0 <= t < max_t on its own.
 // Same records, same order, same early exit, same t as mdp_rc_grid_down / mdp_rc_grid (the CPU oracle's path).
-template <int BATCH>
-__device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_t* m, float ox, float oy, float oz, float dz,
-                                                            float max_t, int* dbg_iters = nullptr) {
-    mdp_hit_t best; best.t = max_t; best.face = -1;
+//
+// One record of the walk: tv = the record's 16 words {a, b, c, face, zmax, zmin, zmax of the next record, ...}.  Updates
+// the best hit and returns whether the walk ends here (`disjoint`: the cell's footprints are pairwise disjoint).
+__device__ __forceinline__ bool mdp_rc_down_exact_record(const float* tv, float ox, float oy, float oz, float Sz,
+                                                         bool disjoint, mdp_hit_t* best) {
+    // (zmax-sorted cells) the test the NEXT record would fail first, made from this record's copy of that record's zmax
+    // once this record has been tried: the next line is not loaded at all
+    #define MDP_RC_NEXT_BELOW()                                                                        \
+        if (!disjoint && best->face >= 0) {                                                            \
+            float t_next = (tv[12] - oz) * Sz;                                                         \
+            if (t_next > best->t + (fabsf(best->t) * 1e-5f + 1e-6f)) return true;                      \
+        }
+    if (best->face >= 0) {
+        float t_reach = (tv[10] - oz) * Sz;
+        if (t_reach > best->t + (fabsf(best->t) * 1e-5f + 1e-6f)) return !disjoint;
+    }
+    float Ax = tv[1] - oy, Ay = tv[0] - ox;
+    float Bx = tv[4] - oy, By = tv[3] - ox;
+    float Cx = tv[7] - oy, Cy = tv[6] - ox;
+    float U = Cx * By - Cy * Bx;
+    float V = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || V == 0.0f || W == 0.0f) {
+        double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
+        U = (float)(CxBy - CyBx);
+        double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
+        V = (float)(AxCy - AyCx);
+        double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
+        W = (float)(BxAy - ByAx);
+    }
+    if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) { MDP_RC_NEXT_BELOW(); return false; }
+    // strictly inside this footprint, in a cell of disjoint footprints: no other record can be touched
+    bool stop = disjoint && ((U > 0.0f && V > 0.0f && W > 0.0f) || (U < 0.0f && V < 0.0f && W < 0.0f));
+    float det = (U + V) + W;
+    if (det == 0.0f) { MDP_RC_NEXT_BELOW(); return stop; }
+    float Az = Sz * (tv[2] - oz), Bz = Sz * (tv[5] - oz), Cz = Sz * (tv[8] - oz);
+    float T = (U * Az + V * Bz) + W * Cz;
+    if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) { MDP_RC_NEXT_BELOW(); return stop; }
+    float rcp = 1.0f / det;
+    float t = T * rcp;
+    if (t >= 0.0f && t < best->t) { best->t = t; best->face = 0; }   // ties on t do not change t
+    MDP_RC_NEXT_BELOW();
+    return stop;
+    #undef MDP_RC_NEXT_BELOW
+}
+
+// the ray's grid cell: false when the ray origin lies outside the (padded) grid, i.e. a miss
+__device__ __forceinline__ bool mdp_rc_down_cell(const mdp_mesh_view_t* m, float ox, float oy, int32_t* cell) {
     float pad = 1e-3f * m->cell + 1e-6f;
     float hix = m->gx0 + m->cell * (float)m->ncx, hiy = m->gy0 + m->cell * (float)m->ncy;
-    if (ox < m->gx0 - pad || ox > hix + pad) return best;
-    if (oy < m->gy0 - pad || oy > hiy + pad) return best;
+    if (ox < m->gx0 - pad || ox > hix + pad) return false;
+    if (oy < m->gy0 - pad || oy > hiy + pad) return false;
     int cx = (int)floorf((ox - m->gx0) * m->inv_cell);
     int cy = (int)floorf((oy - m->gy0) * m->inv_cell);
     if (cx < 0) cx = 0; if (cx >= m->ncx) cx = m->ncx - 1;
     if (cy < 0) cy = 0; if (cy >= m->ncy) cy = m->ncy - 1;
-    int32_t c = cy * m->ncx + cx;
+    *cell = cy * m->ncx + cx;
+    return true;
+}
+
+template <int BATCH>
+__device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_t* m, float ox, float oy, float oz, float dz,
+                                                            float max_t, int* dbg_iters = nullptr) {
+    mdp_hit_t best; best.t = max_t; best.face = -1;
+    int32_t c;
+    if (!mdp_rc_down_cell(m, ox, oy, &c)) return best;
     const int2 cref = reinterpret_cast<const int2*>(m->cell_start)[c];   // one aligned 8-byte load
     const int32_t braw = cref.x;
     const bool disjoint = braw < 0;
@@ -513,47 +589,9 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
             if (i >= n || k + i >= e || stop) continue;
-            const float* tv = R[i].v;
-            // (zmax-sorted cells) the test the NEXT record would fail first, made from this record's copy of that
-            // record's zmax once this record has been tried: the next line is not loaded at all
-            #define MDP_RC_NEXT_BELOW()                                                                    \
-                if (!disjoint && best.face >= 0) {                                                         \
-                    float t_next = (tv[12] - oz) * Sz;                                                     \
-                    if (t_next > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) stop = 1;                       \
-                }
-            if (best.face >= 0) {
-                float t_reach = (tv[10] - oz) * Sz;
-                if (t_reach > best.t + (fabsf(best.t) * 1e-5f + 1e-6f)) { stop = !disjoint; continue; }
-            }
-            float Ax = tv[1] - oy, Ay = tv[0] - ox;
-            float Bx = tv[4] - oy, By = tv[3] - ox;
-            float Cx = tv[7] - oy, Cy = tv[6] - ox;
-            float U = Cx * By - Cy * Bx;
-            float V = Ax * Cy - Ay * Cx;
-            float W = Bx * Ay - By * Ax;
-            if (U == 0.0f || V == 0.0f || W == 0.0f) {
-                double CxBy = (double)Cx * (double)By, CyBx = (double)Cy * (double)Bx;
-                U = (float)(CxBy - CyBx);
-                double AxCy = (double)Ax * (double)Cy, AyCx = (double)Ay * (double)Cx;
-                V = (float)(AxCy - AyCx);
-                double BxAy = (double)Bx * (double)Ay, ByAx = (double)By * (double)Ax;
-                W = (float)(BxAy - ByAx);
-            }
-            if ((U < 0.0f || V < 0.0f || W < 0.0f) && (U > 0.0f || V > 0.0f || W > 0.0f)) { MDP_RC_NEXT_BELOW(); continue; }
-            // strictly inside this footprint, in a cell of disjoint footprints: no other record can be touched
-            if (disjoint && ((U > 0.0f && V > 0.0f && W > 0.0f) || (U < 0.0f && V < 0.0f && W < 0.0f))) stop = 1;
-            float det = (U + V) + W;
-            if (det == 0.0f) { MDP_RC_NEXT_BELOW(); continue; }
-            float Az = Sz * (tv[2] - oz), Bz = Sz * (tv[5] - oz), Cz = Sz * (tv[8] - oz);
-            float T = (U * Az + V * Bz) + W * Cz;
-            if ((det < 0.0f && T > 0.0f) || (det > 0.0f && T < 0.0f)) { MDP_RC_NEXT_BELOW(); continue; }
-            float rcp = 1.0f / det;
-            float t = T * rcp;
-            if (t >= 0.0f && t < best.t) { best.t = t; best.face = 0; }   // ties on t do not change t
-            MDP_RC_NEXT_BELOW();
+            if (mdp_rc_down_exact_record(R[i].v, ox, oy, oz, Sz, disjoint, &best)) stop = 1;
         }
     }
-    #undef MDP_RC_NEXT_BELOW
     return best;
 }
 #endif  // !MDP_RC_HOST

@@ -69,9 +69,10 @@ __device__ __forceinline__ void raycaster_down_ray(const RaycasterUpdateArgs& a,
     mdp_hit_t h;
     if (mesh.finite) {
 #ifdef MDP_STAMPS
-        int walk = 0;   // diagnostic: records in the cell / batches read by this ray (tools/kernel_stamps.py)
-        h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &walk);
-        if (g_stamps) g_stamps[8192 * 8 + (size_t)e * R + r] = (unsigned long long)walk;
+        int walk = 0;   // diagnostic: records in the cell / batches read by this ray, 0 = lattice patch (tools/kernel_stamps.py)
+        if (!(mesh.patch_cells && mdp_rc_patch_down(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &h)))
+            h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &walk);
+        if (g_stamps && e < 4096) g_stamps[8192 * 8 + (size_t)e * R + r] = (unsigned long long)walk;
 #else
         if (!(mesh.patch_cells && mdp_rc_patch_down(&mesh, s.x, s.y, s.z, d.z, a.max_dist, &h)))
             h = mdp_rc_grid_down_exact<BATCH>(&mesh, s.x, s.y, s.z, d.z, a.max_dist);

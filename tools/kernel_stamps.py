@@ -54,7 +54,8 @@ def cast_phases(st):
 
 
 def main():
-    env, rec = make_velocity_env("anymal_c_rough", num_envs=4096, device="cuda:0", steps=8, seed=5, inject_random=False)
+    n_envs = int(os.environ.get("STAMPS_ENVS", "4096"))     # stamp rows exist for 8192 blocks: up to ~7800 envs
+    env, rec = make_velocity_env("anymal_c_rough", num_envs=n_envs, device="cuda:0", steps=8, seed=5, inject_random=False)
     env.observation_manager.persistent_output = True
     reset = os.environ.get("STAMPS_RESET", "0") == "1"      # the launch with the reset branch in it
     if reset:
@@ -95,7 +96,9 @@ def main():
                 print("           manager block that ends last: stamps (us) " +
                       "  ".join("%.2f" % ((last[k] - t0) / 100.0) for k in (0, 1, 2, 3, 4, 6, 5)) + "   (6 = before the log reduction)")
             cast_phases(buf)
-            it = full[8192 * 8:].cpu().numpy().reshape(4096, 187)
+            it = full[8192 * 8:].cpu().numpy().reshape(4096, 187)[: min(n_envs, 4096)]
+            print("           rays answered by the lattice patch: %.3f" % (it == 0).mean())
+            it = np.where(it == 0, 1010, it)
             dis, n, batches = it // 1000, (it % 1000) // 10, it % 10
             print("           rays in disjoint cells %.3f; records per cell mean %.2f; batches per ray mean %.2f  hist %s"
                   % (dis.mean(), n.mean(), batches.mean(), np.bincount(batches.ravel(), minlength=8)[:8].tolist()))
