@@ -36,6 +36,9 @@ struct mdp_program {
     int32_t* d_pool = nullptr;
     RayAux* d_aux = nullptr;
     int16_t* d_col2term = nullptr;
+    // observation columns by evaluation form, for the post-physics kernel: d_col2term + total_cols holds n_opcols
+    // "operand" columns (obs_op_is_operand) followed by n_vterms indices of body-frame vector terms
+    int n_opcols = 0, n_vterms = 0;
     uint64_t* d_rng = nullptr;  // {seed, per-block epoch counters of k_obs, per-64-env-block counters of k_post_physics}
     unsigned rng_post_base = 0; // first k_post_physics counter
     int total_cols = 0;
@@ -68,15 +71,67 @@ MDP_DEV int idx2_at(const mdp_term_t& t, const int32_t* __restrict__ pool, int k
 // number of reduced elements: explicit list length, or the full width stored in i1 for "all"
 MDP_DEV int red_count(const mdp_term_t& t, int full) { return t.n_idx < 0 ? full : t.n_idx; }
 
+// A term that reduces over joints / bodies is one link of the manager blocks' chain of dependent phases, and a loop
+// that loads, waits and accumulates pays one memory round trip per element.  The reductions below therefore REQUEST
+// RED_B elements at a time (indices clamped to the last element, so every request stays inside the row) and then
+// consume them in the reference's left-to-right order: same sums bit for bit, one round trip per RED_B elements.
+constexpr int RED_B = 8;
+#define MDP_RED_IDX(j, k0, n)                                                          \
+    int j[RED_B];                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < RED_B; ++i_) {                             \
+        const int k_ = (k0) + i_ < (n) ? (k0) + i_ : (n) - 1;                          \
+        j[i_] = idx_at(t, pool, k_);                                                   \
+    }
+
 // max over history of |f| for body b: hist (N,H,B,3)
+constexpr int HIST_B = 4;   // history rows requested together (contact_sensor cfgs use history_length <= 3)
 MDP_DEV float contact_hist_max(const float* __restrict__ hist, int e, int H, int B, int b) {
     float m = 0.0f;
+    if (H <= HIST_B) {
+        V3 f[HIST_B];
+#pragma unroll
+        for (int h = 0; h < HIST_B; ++h) {
+            const int hh = h < H ? h : (H > 0 ? H - 1 : 0);
+            if (H > 0) f[h] = ld3(hist + (((int64_t)e * H + hh) * B + b) * 3);
+        }
+#pragma unroll
+        for (int h = 0; h < HIST_B; ++h) {
+            if (h >= H) continue;
+            float n = norm3(f[h]);
+            m = (h == 0) ? n : tmax(m, n);
+        }
+        return m;
+    }
     for (int h = 0; h < H; ++h) {
         const float* f = hist + (((int64_t)e * H + h) * B + b) * 3;
         float n = norm3(ld3(f));
         m = (h == 0) ? n : tmax(m, n);
     }
     return m;
+}
+// the same for two bodies at once (their history rows are requested together)
+MDP_DEV void contact_hist_max2(const float* __restrict__ hist, int e, int H, int B, int b0, int b1, float* m0, float* m1) {
+    if (H > 0 && H <= HIST_B) {
+        V3 f[HIST_B], g[HIST_B];
+#pragma unroll
+        for (int h = 0; h < HIST_B; ++h) {
+            const int hh = h < H ? h : H - 1;
+            f[h] = ld3(hist + (((int64_t)e * H + hh) * B + b0) * 3);
+            g[h] = ld3(hist + (((int64_t)e * H + hh) * B + b1) * 3);
+        }
+        float a = 0.0f, c = 0.0f;
+#pragma unroll
+        for (int h = 0; h < HIST_B; ++h) {
+            if (h >= H) continue;
+            float n = norm3(f[h]), q = norm3(g[h]);
+            a = (h == 0) ? n : tmax(a, n);
+            c = (h == 0) ? q : tmax(c, q);
+        }
+        *m0 = a; *m1 = c;
+        return;
+    }
+    *m0 = contact_hist_max(hist, e, H, B, b0);
+    *m1 = contact_hist_max(hist, e, H, B, b1);
 }
 
 // =============================================================================================
@@ -134,6 +189,79 @@ MDP_DEV float obs_value(const mdp_term_t& t, const int32_t* __restrict__ pool, i
             return (pos[3 * (int64_t)e + 2] - hits[((int64_t)e * t.i0 + k) * 3 + 2]) - t.f0;
         }
         default: return 0.0f;
+    }
+}
+
+// obs_value split in two for the columns whose value is a function of at most three loaded words ("operand" ops:
+// everything but the body-frame vectors and the columns other launches write): the addresses, and what is done with the
+// loaded words.  The post-physics kernel requests the operands of several columns before it uses any of them.
+MDP_DEV bool obs_op_is_operand(int op) {
+    return op == MDP_OBS_COPY || op == MDP_OBS_SUB || op == MDP_OBS_ADD_ROW_BIAS || op == MDP_OBS_ROOT_QUAT_UNIQUE ||
+           op == MDP_OBS_JOINT_POS_LIMIT_NORMALIZED || op == MDP_OBS_HEIGHT_SCAN;
+}
+MDP_DEV bool obs_op_is_vector(int op) {
+    return op == MDP_OBS_BASE_LIN_VEL || op == MDP_OBS_BASE_ANG_VEL || op == MDP_OBS_PROJECTED_GRAVITY;
+}
+MDP_DEV void obs_operand_addrs(const mdp_term_t& t, const int32_t* __restrict__ pool, int e, int k, const float** pa,
+                               const float** pb, const float** pc) {
+    const float* a;
+    const float* b;
+    const float* c;
+    switch (t.op) {
+        case MDP_OBS_SUB: {
+            int j = idx_at(t, pool, k);
+            a = (const float*)t.p0 + ((int64_t)e * t.i0 + t.i1 + j);
+            b = (const float*)t.p1 + ((int64_t)e * t.i2 + t.i3 + j);
+            c = a;
+            break;
+        }
+        case MDP_OBS_ADD_ROW_BIAS: {
+            a = (const float*)t.p0 + ((int64_t)e * t.i0 + t.i1 + idx_at(t, pool, k));
+            b = (const float*)t.p1 + ((int64_t)e * t.i2 + t.i3);
+            c = a;
+            break;
+        }
+        case MDP_OBS_ROOT_QUAT_UNIQUE: {
+            const float* r = (const float*)t.p0 + (int64_t)e * t.i0;
+            a = r + 3 + k;
+            b = r + 3;
+            c = a;
+            break;
+        }
+        case MDP_OBS_JOINT_POS_LIMIT_NORMALIZED: {
+            int j = idx_at(t, pool, k);
+            a = (const float*)t.p0 + ((int64_t)e * t.i0 + j);
+            b = (const float*)t.p1 + ((int64_t)e * t.i1 + j) * 2;
+            c = b + 1;
+            break;
+        }
+        case MDP_OBS_HEIGHT_SCAN: {
+            a = (const float*)t.p0 + (3 * (int64_t)e + 2);
+            b = (const float*)t.p1 + (((int64_t)e * t.i0 + k) * 3 + 2);
+            c = a;
+            break;
+        }
+        default: {   // MDP_OBS_COPY
+            a = (const float*)t.p0 + ((int64_t)e * t.i0 + t.i1 + idx_at(t, pool, k));
+            b = a;
+            c = a;
+            break;
+        }
+    }
+    *pa = a; *pb = b; *pc = c;
+}
+// same expressions as obs_value
+MDP_DEV float obs_operand_finish(const mdp_term_t& t, float a, float b, float c) {
+    switch (t.op) {
+        case MDP_OBS_SUB: return a - b;
+        case MDP_OBS_ADD_ROW_BIAS: return a + b;
+        case MDP_OBS_ROOT_QUAT_UNIQUE: return b < 0.0f ? -a : a;
+        case MDP_OBS_JOINT_POS_LIMIT_NORMALIZED: {
+            float offset = (b + c) * 0.5f;
+            return 2.0f * (a - offset) / (c - b);
+        }
+        case MDP_OBS_HEIGHT_SCAN: return (a - b) - t.f0;
+        default: return a;
     }
 }
 
@@ -333,21 +461,42 @@ MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool
             const float* acc = (const float*)t.p0;
             int B = t.i1, n = red_count(t, B);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) s += norm3(ld3(acc + ((int64_t)e * B + idx_at(t, pool, k)) * 6));
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                V3 v[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) v[i] = ld3(acc + ((int64_t)e * B + j[i]) * 6);
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) if (k0 + i < n) s += norm3(v[i]);
+            }
             return s;
         }
         case MDP_REW_SUM_SQ: {
             const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
             int n = red_count(t, t.i1);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) { float v = p[idx_at(t, pool, k)]; s += v * v; }
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) v[i] = p[j[i]];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) if (k0 + i < n) s += v[i] * v[i];
+            }
             return s;
         }
         case MDP_REW_SUM_ABS: {
             const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
             int n = red_count(t, t.i1);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) s += fabsf(p[idx_at(t, pool, k)]);
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) v[i] = p[j[i]];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) if (k0 + i < n) s += fabsf(v[i]);
+            }
             return s;
         }
         case MDP_REW_SUM_ABS_DIFF:
@@ -356,10 +505,17 @@ MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool
             const float* q = (const float*)t.p1 + (int64_t)e * t.i2;
             int n = red_count(t, t.i1);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                int j = idx_at(t, pool, k);
-                float d = p[j] - q[j];
-                s += (t.op == MDP_REW_SUM_ABS_DIFF) ? fabsf(d) : d * d;
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B], w[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) { v[i] = p[j[i]]; w[i] = q[j[i]]; }
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) {
+                    if (k0 + i >= n) continue;
+                    float d = v[i] - w[i];
+                    s += (t.op == MDP_REW_SUM_ABS_DIFF) ? fabsf(d) : d * d;
+                }
             }
             return s;
         }
@@ -368,11 +524,18 @@ MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool
             const float* lim = (const float*)t.p1 + (int64_t)e * t.i1 * 2;
             int n = red_count(t, t.i1);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                int j = idx_at(t, pool, k);
-                float o = -tclamp_max(p[j] - lim[2 * j], 0.0f);
-                o = o + tclamp_min(p[j] - lim[2 * j + 1], 0.0f);
-                s += o;
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B], lo[RED_B], hi[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) { v[i] = p[j[i]]; lo[i] = lim[2 * j[i]]; hi[i] = lim[2 * j[i] + 1]; }
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) {
+                    if (k0 + i >= n) continue;
+                    float o = -tclamp_max(v[i] - lo[i], 0.0f);
+                    o = o + tclamp_min(v[i] - hi[i], 0.0f);
+                    s += o;
+                }
             }
             return s;
         }
@@ -381,9 +544,13 @@ MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool
             const float* lim = (const float*)t.p1 + (int64_t)e * t.i1;
             int n = red_count(t, t.i1);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                int j = idx_at(t, pool, k);
-                s += tclamp(fabsf(p[j]) - lim[j] * t.f0, 0.0f, 1.0f);
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B], l[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) { v[i] = p[j[i]]; l[i] = lim[j[i]]; }
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) if (k0 + i < n) s += tclamp(fabsf(v[i]) - l[i] * t.f0, 0.0f, 1.0f);
             }
             return s;
         }
@@ -392,10 +559,14 @@ MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool
             const float* hist = (const float*)t.p0;
             int H = t.i0, B = t.i1, n = red_count(t, B);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                float m = contact_hist_max(hist, e, H, B, idx_at(t, pool, k));
-                if (t.op == MDP_REW_UNDESIRED_CONTACTS) s += (m > t.f0) ? 1.0f : 0.0f;
-                else s += tclamp_min(m - t.f0, 0.0f);
+            for (int k = 0; k < n; k += 2) {
+                float m0, m1;
+                contact_hist_max2(hist, e, H, B, idx_at(t, pool, k), idx_at(t, pool, k + 1 < n ? k + 1 : k), &m0, &m1);
+                if (t.op == MDP_REW_UNDESIRED_CONTACTS) s += (m0 > t.f0) ? 1.0f : 0.0f;
+                else s += tclamp_min(m0 - t.f0, 0.0f);
+                if (k + 1 >= n) break;
+                if (t.op == MDP_REW_UNDESIRED_CONTACTS) s += (m1 > t.f0) ? 1.0f : 0.0f;
+                else s += tclamp_min(m1 - t.f0, 0.0f);
             }
             return s;
         }
@@ -420,12 +591,20 @@ MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool
             const float* c = (const float*)t.p2 + (int64_t)e * t.i2;
             int n = red_count(t, t.i1);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                int b = idx_at(t, pool, k);
-                float first = ((tc[b] > 0.0f) && (tc[b] < t.f1)) ? 1.0f : 0.0f;
-                s += (la[b] - t.f0) * first;
+            const float cx = c[0], cy = c[1];
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B], w[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) { v[i] = tc[j[i]]; w[i] = la[j[i]]; }
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) {
+                    if (k0 + i >= n) continue;
+                    float first = ((v[i] > 0.0f) && (v[i] < t.f1)) ? 1.0f : 0.0f;
+                    s += (w[i] - t.f0) * first;
+                }
             }
-            return s * ((norm2(c[0], c[1]) > 0.1f) ? 1.0f : 0.0f);
+            return s * ((norm2(cx, cy) > 0.1f) ? 1.0f : 0.0f);
         }
         case MDP_REW_FEET_AIR_TIME_POSITIVE_BIPED: {
             const float* air = (const float*)t.p0 + (int64_t)e * t.i1;
@@ -450,10 +629,16 @@ MDP_DEV float reward_value(const mdp_term_t& t, const int32_t* __restrict__ pool
             const float* body = (const float*)t.p1;
             int H = t.i0, Bs = t.i1, Ba = t.i2, n = red_count(t, Bs);
             float s = 0.0f;
-            for (int k = 0; k < n; ++k) {
-                float contact = contact_hist_max(hist, e, H, Bs, idx_at(t, pool, k)) > 1.0f ? 1.0f : 0.0f;
-                const float* bs = body + ((int64_t)e * Ba + idx2_at(t, pool, k)) * 13;
-                s += norm2(bs[7], bs[8]) * contact;
+            for (int k = 0; k < n; k += 2) {
+                const int k1 = k + 1 < n ? k + 1 : k;
+                const float* bs0 = body + ((int64_t)e * Ba + idx2_at(t, pool, k)) * 13;
+                const float* bs1 = body + ((int64_t)e * Ba + idx2_at(t, pool, k1)) * 13;
+                const float vx0 = bs0[7], vy0 = bs0[8], vx1 = bs1[7], vy1 = bs1[8];
+                float m0, m1;
+                contact_hist_max2(hist, e, H, Bs, idx_at(t, pool, k), idx_at(t, pool, k1), &m0, &m1);
+                s += norm2(vx0, vy0) * (m0 > 1.0f ? 1.0f : 0.0f);
+                if (k + 1 >= n) break;
+                s += norm2(vx1, vy1) * (m1 > 1.0f ? 1.0f : 0.0f);
             }
             return s;
         }
@@ -527,10 +712,17 @@ MDP_DEV bool term_value(const mdp_term_t& t, const int32_t* __restrict__ pool, i
             const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
             int n = red_count(t, t.i1);
             bool up = false, lo = false;
-            for (int k = 0; k < n; ++k) {
-                float v = p[idx_at(t, pool, k)];
-                up = up || (v > t.f1);
-                lo = lo || (v < t.f0);
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) v[i] = p[j[i]];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) {
+                    if (k0 + i >= n) continue;
+                    up = up || (v[i] > t.f1);
+                    lo = lo || (v[i] < t.f0);
+                }
             }
             return up || lo;
         }
@@ -539,14 +731,28 @@ MDP_DEV bool term_value(const mdp_term_t& t, const int32_t* __restrict__ pool, i
             const float* lim = (const float*)t.p1 + (int64_t)e * t.i1;
             int n = red_count(t, t.i1);
             bool any = false;
-            for (int k = 0; k < n; ++k) { int j = idx_at(t, pool, k); any = any || (fabsf(p[j]) > lim[j]); }
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B], l[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) { v[i] = p[j[i]]; l[i] = lim[j[i]]; }
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) if (k0 + i < n) any = any || (fabsf(v[i]) > l[i]);
+            }
             return any;
         }
         case MDP_TERM_JOINT_VEL_OUT_OF_MANUAL_LIMIT: {
             const float* p = (const float*)t.p0 + (int64_t)e * t.i0;
             int n = red_count(t, t.i1);
             bool any = false;
-            for (int k = 0; k < n; ++k) any = any || (fabsf(p[idx_at(t, pool, k)]) > t.f0);
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+                MDP_RED_IDX(j, k0, n);
+                float v[RED_B];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) v[i] = p[j[i]];
+#pragma unroll
+                for (int i = 0; i < RED_B; ++i) if (k0 + i < n) any = any || (fabsf(v[i]) > t.f0);
+            }
             return any;
         }
         case MDP_TERM_JOINT_EFFORT_OUT_OF_LIMIT: {
@@ -555,11 +761,18 @@ MDP_DEV bool term_value(const mdp_term_t& t, const int32_t* __restrict__ pool, i
             const float* b = (const float*)t.p1 + (int64_t)e * t.i0;
             int n = red_count(t, t.i1);
             bool any = false;
-            for (int k = 0; k < n; ++k) {
-                int j = idx_at(t, pool, k);
-                float x = a[j], y = b[j];
+            for (int k0 = 0; k0 < n; k0 += RED_B) {
+              MDP_RED_IDX(j, k0, n);
+              float xs[RED_B], ys[RED_B];
+#pragma unroll
+              for (int i = 0; i < RED_B; ++i) { xs[i] = a[j[i]]; ys[i] = b[j[i]]; }
+#pragma unroll
+              for (int i = 0; i < RED_B; ++i) {
+                if (k0 + i >= n) continue;
+                float x = xs[i], y = ys[i];
                 bool close = (x == y) || (isfinite(x) && isfinite(y) && (fabsf(x - y) <= 1e-8f + 1e-5f * fabsf(y)));
                 any = any || close;
+              }
             }
             return any;
         }
@@ -567,7 +780,12 @@ MDP_DEV bool term_value(const mdp_term_t& t, const int32_t* __restrict__ pool, i
             const float* hist = (const float*)t.p0;
             int H = t.i0, B = t.i1, n = red_count(t, B);
             bool any = false;
-            for (int k = 0; k < n; ++k) any = any || (contact_hist_max(hist, e, H, B, idx_at(t, pool, k)) > t.f0);
+            for (int k = 0; k < n; k += 2) {
+                float m0, m1;
+                contact_hist_max2(hist, e, H, B, idx_at(t, pool, k), idx_at(t, pool, k + 1 < n ? k + 1 : k), &m0, &m1);
+                any = any || (m0 > t.f0);
+                if (k + 1 < n) any = any || (m1 > t.f0);
+            }
             return any;
         }
         case MDP_TERM_TERRAIN_OUT_OF_BOUNDS: {
@@ -681,14 +899,20 @@ struct PostArgs {
     int has_cmd;
     mdp_velocity_command_args_t cmd;
     const mdp_term_t* oterms; int To; const int32_t* opool; const int16_t* col2term; int O;
+    const int16_t* olists; int n_opcols, n_vterms;   // operand columns, then vector terms (mdp_program::n_opcols)
     float* obs; int ld_obs; uint64_t* orng; unsigned orng_base; int ouses_rng;
     mdp_obs_normalize_t onorm;
     // ---- reset branch (k_post_physics<.., true> only)
     const mdp_fill_t* fills; int num_fills; float max_episode_length_s; double* log_sums; float* log;
 };
 
+// Both roles of the kernel are chains of dependent memory round trips, so the waves a CU can hold are its throughput:
+// the register budget is set for MDP_POST_MIN_WAVES waves per SIMD (the few values that do not fit live in scratch).
+#ifndef MDP_POST_MIN_WAVES
+#define MDP_POST_MIN_WAVES 6
+#endif
 template <int BATCH, bool RESET>
-__global__ void __launch_bounds__(256) k_post_physics(PostArgs a) {
+__global__ void __launch_bounds__(256, MDP_POST_MIN_WAVES) k_post_physics(PostArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
         MDP_STAMP(0, 1);
@@ -721,10 +945,13 @@ __global__ void __launch_bounds__(256) k_post_physics(PostArgs a) {
         for (int i = threadIdx.x; i < wo + wt + wr; i += blockDim.x)
             dst[i] = i < wo ? so[i] : (i < wo + wt ? st[i - wo] : sr[i - wo - wt]);
         for (int i = threadIdx.x; i < a.O; i += blockDim.x) col2term[i] = a.col2term[i];
+        for (int i = threadIdx.x; i < a.n_opcols + a.n_vterms; i += blockDim.x) col2term[a.O + i] = a.olists[i];
     }
+    const int16_t* opcols = col2term + a.O;
+    const int16_t* vterms = opcols + a.n_opcols;
     // reset variant: the fill records behind the column map (8-byte aligned), the block's done flags in s_done
     mdp_fill_t* fills = reinterpret_cast<mdp_fill_t*>(
-        s_dyn + (((size_t)(reinterpret_cast<unsigned char*>(col2term + a.O) - s_dyn) + 7) & ~(size_t)7));
+        s_dyn + (((size_t)(reinterpret_cast<unsigned char*>(col2term + a.O + a.n_opcols + a.n_vterms) - s_dyn) + 7) & ~(size_t)7));
     __shared__ uint8_t s_done[64];
     __shared__ int s_last;
     if (RESET) {
@@ -883,21 +1110,53 @@ __global__ void __launch_bounds__(256) k_post_physics(PostArgs a) {
         // own counters, tagged so that a draw never repeats one made by k_obs for the same element
         if (a.ouses_rng) { seed = a.orng[0]; epoch = a.orng[a.orng_base + b]; }
         const int O = a.O;
-        const int total = (e1 - e0) * O;
-        for (int i = threadIdx.x; i < total; i += blockDim.x) {
-            int le = i / O;
-            int c = i - le * O;
-            int ee = e0 + le;
-            int ti = col2term[c];
-            const mdp_term_t& t = oterms[ti];
-            if (t.op == MDP_OBS_SKIP || t.op == MDP_OBS_HEIGHT_SCAN_CAST) continue;
-            int k = c - t.out_offset;
-            float v = obs_value(t, a.opool, ee, k);
+        const int ne = e1 - e0;
+        auto emit = [&](const mdp_term_t& t, int ti, int ee, int c, int k, float v) {
             v = obs_post(t, v, ee, k, seed, epoch | (1ull << 62), 0x4f425300u + (uint32_t)ti, (uint64_t)ee * (uint64_t)O + c);
             a.obs[(int64_t)ee * a.ld_obs + c] = v;
             if (a.onorm.out)     // the standardised copy for the observation's consumer (mdp_obs_normalize_t)
                 a.onorm.out[(int64_t)ee * a.onorm.ld_out + c] =
                     tclamp((v - a.onorm.mean32[c]) / a.onorm.denom[c], -a.onorm.clip, a.onorm.clip);
+        };
+        // (1) operand columns, columns fastest.  A thread requests the operands of OBS_U of its items before it
+        // finishes the first: the phase costs one memory round trip per OBS_U items instead of one per item (items
+        // past the end repeat the last one's requests and store nothing)
+        constexpr int OBS_U = 4;
+        const int total = ne * a.n_opcols;
+        for (int i0 = threadIdx.x; i0 < total; i0 += OBS_U * blockDim.x) {
+            float va[OBS_U], vb[OBS_U], vc[OBS_U];
+            int ees[OBS_U], cs[OBS_U];
+#pragma unroll
+            for (int u = 0; u < OBS_U; ++u) {
+                int i = i0 + u * (int)blockDim.x;
+                if (i >= total) i = total - 1;
+                const int le = i / a.n_opcols;
+                const int c = opcols[i - le * a.n_opcols];
+                const mdp_term_t& t = oterms[col2term[c]];
+                const float *pa, *pb, *pc;
+                obs_operand_addrs(t, a.opool, e0 + le, c - t.out_offset, &pa, &pb, &pc);
+                va[u] = *pa; vb[u] = *pb; vc[u] = *pc;
+                ees[u] = e0 + le; cs[u] = c;
+            }
+#pragma unroll
+            for (int u = 0; u < OBS_U; ++u) {
+                if (i0 + u * (int)blockDim.x >= total) continue;
+                const int ti = col2term[cs[u]];
+                const mdp_term_t& t = oterms[ti];
+                emit(t, ti, ees[u], cs[u], cs[u] - t.out_offset, obs_operand_finish(t, va[u], vb[u], vc[u]));
+            }
+        }
+        // (2) body-frame vector terms: one thread per (env, term) rotates once and writes the term's three columns
+        for (int i = threadIdx.x; i < ne * a.n_vterms; i += blockDim.x) {
+            const int le = i / a.n_vterms;
+            const int ti = vterms[i - le * a.n_vterms];
+            const mdp_term_t& t = oterms[ti];
+            const int ee = e0 + le;
+            const float* r = (const float*)t.p0 + (int64_t)ee * t.i0;
+            V3 v = t.op == MDP_OBS_PROJECTED_GRAVITY ? V3{t.f0, t.f1, t.f2} : ld3(r + (t.op == MDP_OBS_BASE_LIN_VEL ? 7 : 10));
+            v = quat_rotate_inverse(ld4(r + 3), v);
+            for (int k = 0; k < t.dim && k < 3; ++k)
+                if (t.out_offset + k < O) emit(t, ti, ee, t.out_offset + k, k, get(v, k));
         }
         if (a.ouses_rng && threadIdx.x == 0) a.orng[a.orng_base + b] = epoch + 1;
     }
@@ -981,6 +1240,14 @@ __global__ void k_term_single(mdp_term_t t, const int32_t* __restrict__ pool, in
 // =============================================================================================
 // Host API
 // =============================================================================================
+static bool obs_op_is_operand_host(int op) {
+    return op == MDP_OBS_COPY || op == MDP_OBS_SUB || op == MDP_OBS_ADD_ROW_BIAS || op == MDP_OBS_ROOT_QUAT_UNIQUE ||
+           op == MDP_OBS_JOINT_POS_LIMIT_NORMALIZED || op == MDP_OBS_HEIGHT_SCAN;
+}
+static bool obs_op_is_vector_host(int op) {
+    return op == MDP_OBS_BASE_LIN_VEL || op == MDP_OBS_BASE_ANG_VEL || op == MDP_OBS_PROJECTED_GRAVITY;
+}
+
 extern "C" int mdp_program_create(int kind, int device, int num_envs, const mdp_term_t* terms, int num_terms,
                                   const int32_t* index_pool, int index_pool_len, uint64_t seed,
                                   mdp_program_t** out) {
@@ -1059,8 +1326,16 @@ extern "C" int mdp_program_create(int kind, int device, int num_envs, const mdp_
     if (index_pool_len)
         MDP_CHECK_HIP(hipMemcpy(p->d_pool, index_pool, sizeof(int32_t) * (size_t)index_pool_len, hipMemcpyHostToDevice));
     if (!col2term.empty()) {
-        MDP_CHECK_HIP(dmalloc((void**)&p->d_col2term, sizeof(int16_t) * col2term.size()));
-        MDP_CHECK_HIP(hipMemcpy(p->d_col2term, col2term.data(), sizeof(int16_t) * col2term.size(), hipMemcpyHostToDevice));
+        std::vector<int16_t> tab(col2term);
+        for (int c = 0; c < p->active_cols; ++c)
+            if (obs_op_is_operand_host(p->h_terms[col2term[c]].op)) { tab.push_back((int16_t)c); ++p->n_opcols; }
+        for (int i = 0; i < num_terms; ++i)
+            if (obs_op_is_vector_host(p->h_terms[i].op) && p->h_terms[i].out_offset < p->active_cols) {
+                tab.push_back((int16_t)i);
+                ++p->n_vterms;
+            }
+        MDP_CHECK_HIP(dmalloc((void**)&p->d_col2term, sizeof(int16_t) * tab.size()));
+        MDP_CHECK_HIP(hipMemcpy(p->d_col2term, tab.data(), sizeof(int16_t) * tab.size(), hipMemcpyHostToDevice));
     }
     {
         // {seed, epoch of block 0, epoch of block 1, ...}: one counter per block of the observation grid
@@ -1216,7 +1491,12 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         }
         a.cast_epb = cast->num_rays >= threads ? 1 : std::min(threads / cast->num_rays, (int)RCU_MAX_EPB);
         a.cast_slot_w = cast->num_rays >= threads ? threads : cast->num_rays;
-        a.nb_cast = (unsigned)std::min<int64_t>(((int64_t)num_envs + a.cast_epb - 1) / a.cast_epb, 1 << 20);
+        static const int64_t cast_cap = [] {
+            const char* v = std::getenv("MDP_POST_CAST_BLOCKS");   // > 0: at most this many cast blocks, each strides over its envs
+            int64_t c = v ? std::atoll(v) : 0;
+            return c > 0 ? c : (int64_t)(1 << 20);
+        }();
+        a.nb_cast = (unsigned)std::min<int64_t>(((int64_t)num_envs + a.cast_epb - 1) / a.cast_epb, cast_cap);
     }
     // ---- scene update
     if (update) {
@@ -1253,6 +1533,7 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         MDP_REQUIRE(observation->obs && observation->ld_obs >= op->total_cols, "obs buffer too narrow");
         if (op->active_cols > 0) {
             a.oterms = op->d_terms; a.To = op->num_terms; a.opool = op->d_pool; a.col2term = op->d_col2term;
+            a.olists = op->d_col2term + op->total_cols; a.n_opcols = op->n_opcols; a.n_vterms = op->n_vterms;
             a.O = op->active_cols; a.obs = observation->obs; a.ld_obs = observation->ld_obs; a.orng = op->d_rng; a.orng_base = op->rng_post_base;
             a.ouses_rng = op->uses_rng;
             if (observation->normalize.out) {
@@ -1260,7 +1541,8 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
                                 observation->normalize.ld_out >= op->total_cols, "observation normalize: bad tables / ld_out");
                 a.onorm = observation->normalize;
             }
-            lds += (size_t)op->num_terms * sizeof(mdp_term_t) + (size_t)a.O * sizeof(int16_t) + 16;
+            lds += (size_t)op->num_terms * sizeof(mdp_term_t) +
+                   (size_t)(a.O + a.n_opcols + a.n_vterms) * sizeof(int16_t) + 16;
         }
     }
     if (reset && reset->num_fills > 0) lds += (size_t)reset->num_fills * sizeof(mdp_fill_t) + 8;

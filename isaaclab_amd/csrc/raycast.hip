@@ -869,6 +869,11 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
     }
     if (pattern_vertical_down && attach_yaw_only && mesh->view.accel == 1 && mesh->view.cell_recs) {
         static const int batch = [] { const char* b = std::getenv("MDP_RC_BATCH"); return b ? std::atoi(b) : 1; }();
+        static const int64_t block_cap = [] {   // > 0: at most this many blocks, each strides over its envs
+            const char* b = std::getenv("MDP_RC_BLOCKS");
+            int64_t c = b ? std::atoll(b) : 0;
+            return c > 0 ? c : (int64_t)(1 << 20);
+        }();
         RaycasterUpdateArgs ra;
         ra.mesh = mesh->view; ra.N = num_envs; ra.R = num_rays; ra.pose = root_pose; ra.ld_pose = ld_pose;
         ra.pose_xyzw = pose_xyzw; ra.drift = drift; ra.starts_l = ray_starts_local; ra.dirs_l = ray_dirs_local;
@@ -876,7 +881,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
         ra.ts_last = timestamp_last_update; ra.outdated = is_outdated; ra.scan = sc; ra.tick_dt = tick_dt;
         ra.period = update_period; ra.reset_mask = nullptr;
 #define RCD_LAUNCH(B)                                                                                             \
-    hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, 1 << 20)), dim3(threads), 0,          \
+    hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, block_cap)), dim3(threads), 0,        \
                        as_stream(stream), ra, epb, slot_w)
         if (batch == 1) RCD_LAUNCH(1); else if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
 #undef RCD_LAUNCH

@@ -152,6 +152,37 @@ def _env_cfg(name: str, num_envs: int, network=None):
     return cfg
 
 
+def make_rough_terrain(num_envs: int, small: bool = False, seed: int = 42, generator: str | None = None):
+    """The terrain of the rough velocity tasks: ``ROUGH_TERRAINS_CFG`` (LAB/terrains/config/rough.py:12-51) through the
+    restated ``TerrainGenerator`` with the curriculum layout the task cfg switches on (velocity_env_cfg.py:314-318) and
+    ``max_init_terrain_level = 5`` (velocity_env_cfg.py:60) -- 10 x 20 tiles, ~1.19 M triangles; ``small``: 2 x 10 tiles
+    (every sub-terrain type once per row), levels 0..1.  The generator reads numpy's and torch's global generators (like
+    the reference); both are seeded for the build and restored afterwards.
+    ``generator='synthetic'`` (or ``MDP_TERRAIN=synthetic``): the round-1 look-alike (``SyntheticTerrain``)."""
+    import os
+
+    from ..terrains import SyntheticTerrain, SyntheticTerrainCfg
+    from ..terrains.synthetic import TerrainGeneratorCfg as SyntheticGeneratorCfg
+    from ..terrains.terrain_generator import ROUGH_TERRAINS_CFG, GeneratedTerrain, TerrainImporterCfg
+
+    if (generator or os.environ.get("MDP_TERRAIN", "generator")) == "synthetic":
+        gen = SyntheticGeneratorCfg(num_rows=2, num_cols=5) if small else SyntheticGeneratorCfg()
+        return SyntheticTerrain(SyntheticTerrainCfg(terrain_generator=gen, max_init_terrain_level=1 if small else 5), num_envs)
+    cfg = ROUGH_TERRAINS_CFG.copy()
+    cfg.curriculum, cfg.seed = True, seed
+    if small:
+        cfg.num_rows, cfg.num_cols = 2, 10
+    np_state = np.random.get_state()
+    with torch.random.fork_rng(devices=[]):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        try:
+            return GeneratedTerrain(TerrainImporterCfg(terrain_generator=cfg, max_init_terrain_level=1 if small else 5,
+                                                       num_envs=num_envs), num_envs)
+        finally:
+            np.random.set_state(np_state)
+
+
 def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: int = 8, seed: int = 0,
                       small_terrain: bool = False, inject_random: bool = True, network=None, terrain=None,
                       mesh_accel: str = "auto", events: bool = False):
@@ -159,8 +190,6 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
 
     ``inject_random=True`` replaces the device generators of the command term and of the observation noise by
     recorded uniforms (parity tests); ``False`` leaves the device-side Philox generators on (benchmark)."""
-    from ..terrains import SyntheticTerrain, SyntheticTerrainCfg
-    from ..terrains.synthetic import TerrainGeneratorCfg
     from .manager_based_rl_env import ManagerBasedRLEnv
 
     if name == "anymal_c_rough" and network is None:
@@ -176,9 +205,7 @@ def make_velocity_env(name: str, num_envs: int, device: str = "cuda:0", steps: i
 
         cfg.curriculum = CurriculumCfg()
     if terrain is None and rough:
-        gen = TerrainGeneratorCfg(num_rows=2, num_cols=5) if small_terrain else TerrainGeneratorCfg()
-        terrain = SyntheticTerrain(SyntheticTerrainCfg(terrain_generator=gen, max_init_terrain_level=1 if small_terrain else 5),
-                                   num_envs)
+        terrain = make_rough_terrain(num_envs, small=small_terrain)
     mesh = None
     if rough and mesh_accel != "auto":     # tests: pin the acceleration structure (and with it the cast kernel)
         from ..utils.warp import convert_to_warp_mesh

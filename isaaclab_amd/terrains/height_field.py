@@ -27,33 +27,14 @@ class TriMesh(NamedTuple):
 class HfTerrainBaseCfg:
     """hf_terrains_cfg.py:16-32 (+ the sub-terrain fields the functions read)."""
 
+    function: object = None            # the generator (hf_terrains_cfg.py:41,69,108)
+    proportion: float = 1.0
+    flat_patch_sampling: dict | None = None
     size: tuple = (8.0, 8.0)
     border_width: float = 0.0
     horizontal_scale: float = 0.1
     vertical_scale: float = 0.005
     slope_threshold: float | None = None
-
-
-@configclass
-class HfRandomUniformTerrainCfg(HfTerrainBaseCfg):
-    noise_range: tuple = (0.02, 0.10)
-    noise_step: float = 0.02
-    downsampled_scale: float | None = None
-
-
-@configclass
-class HfPyramidSlopedTerrainCfg(HfTerrainBaseCfg):
-    slope_range: tuple = (0.0, 0.4)
-    platform_width: float = 1.0
-    inverted: bool = False
-
-
-@configclass
-class HfPyramidStairsTerrainCfg(HfTerrainBaseCfg):
-    step_height_range: tuple = (0.05, 0.23)
-    step_width: float = 0.3
-    platform_width: float = 1.0
-    inverted: bool = False
 
 
 def _pixels(cfg):
@@ -143,3 +124,46 @@ def pyramid_stairs_terrain(difficulty: float, cfg: HfPyramidStairsTerrainCfg) ->
         x0, x1, y0, y1, level = x0 + run, x1 - run, y0 + run, y1 - run, level + rise
         field[x0:x1, y0:y1] = level
     return np.rint(field).astype(np.int16)
+
+
+# ---- configs (hf_terrains_cfg.py:34-136): defined behind the generators they name ----
+
+
+@configclass
+class HfRandomUniformTerrainCfg(HfTerrainBaseCfg):
+    function = random_uniform_terrain
+    noise_range: tuple = (0.02, 0.10)
+    noise_step: float = 0.02
+    downsampled_scale: float | None = None
+
+
+@configclass
+class HfPyramidSlopedTerrainCfg(HfTerrainBaseCfg):
+    function = pyramid_sloped_terrain
+    slope_range: tuple = (0.0, 0.4)
+    platform_width: float = 1.0
+    inverted: bool = False
+
+
+@configclass
+class HfPyramidStairsTerrainCfg(HfTerrainBaseCfg):
+    function = pyramid_stairs_terrain
+    step_height_range: tuple = (0.05, 0.23)
+    step_width: float = 0.3
+    platform_width: float = 1.0
+    inverted: bool = False
+
+
+@configclass
+class HfInvertedPyramidSlopedTerrainCfg(HfPyramidSlopedTerrainCfg):
+    """hf_terrains_cfg.py:88-97."""
+
+    inverted: bool = True
+
+
+@configclass
+class HfInvertedPyramidStairsTerrainCfg(HfPyramidStairsTerrainCfg):
+    """hf_terrains_cfg.py:127-136."""
+
+    inverted: bool = True
+

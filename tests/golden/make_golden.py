@@ -1247,6 +1247,100 @@ def gen_terrains():
     save("terrains", **out)
 
 
+def gen_mesh_terrains():
+    """Mesh sub-terrains and the whole generator run by the REFERENCE (trimesh/mesh_terrains.py, trimesh/utils.py,
+    terrain_generator.py) on the trimesh stand-in of tests/golden/trimesh_standin.py (trimesh is absent: its box
+    layout is restated there, everything else is the reference's own code).  Stored: triangle soups in face order
+    (fp32, what convert_to_warp_mesh receives), origins, and for the full ROUGH_TERRAINS_CFG a digest + samples."""
+    import hashlib
+    import trimesh_standin
+
+    sys.modules["trimesh"] = trimesh_standin.module()
+    for name in ("isaaclab.terrains.trimesh", "isaaclab.terrains.trimesh.utils"):
+        sys.modules.pop(name, None)
+    # a plain package object for isaaclab.terrains (the attribute-swallowing stub would answer the circular
+    # `import isaaclab.terrains.trimesh.mesh_terrains as ...` of mesh_terrains_cfg.py with a dummy)
+    plain = types.ModuleType("isaaclab.terrains")
+    plain.__path__ = list(sys.modules["isaaclab.terrains"].__path__)
+    sys.modules["isaaclab.terrains"] = plain
+    sys.modules["isaaclab"].terrains = plain
+    mtc = R.ref_import("isaaclab.terrains.trimesh.mesh_terrains_cfg")
+    hfc = R.ref_import("isaaclab.terrains.height_field.hf_terrains_cfg")
+    tg = R.ref_import("isaaclab.terrains.terrain_generator")
+    tgc = R.ref_import("isaaclab.terrains.terrain_generator_cfg")
+
+    def soup(mesh):
+        return np.asarray(mesh.vertices, np.float64)[np.asarray(mesh.faces)].astype(np.float32)
+
+    out = {}
+    cat = sys.modules["trimesh"].util.concatenate
+    subs = {
+        "stairs": (mtc.MeshPyramidStairsTerrainCfg(size=(8.0, 8.0), step_height_range=(0.05, 0.23), step_width=0.3,
+                                                   platform_width=3.0, border_width=1.0, holes=False), 0.37),
+        "stairs_inv": (mtc.MeshInvertedPyramidStairsTerrainCfg(size=(8.0, 8.0), step_height_range=(0.05, 0.23), step_width=0.3,
+                                                               platform_width=3.0, border_width=1.0, holes=False), 0.81),
+        "stairs_holes": (mtc.MeshPyramidStairsTerrainCfg(size=(6.0, 7.0), step_height_range=(0.1, 0.2), step_width=0.25,
+                                                         platform_width=1.5, border_width=0.0, holes=True), 0.5),
+        "boxes": (mtc.MeshRandomGridTerrainCfg(size=(8.0, 8.0), grid_width=0.45, grid_height_range=(0.05, 0.2), platform_width=2.0), 0.6),
+        "boxes_holes": (mtc.MeshRandomGridTerrainCfg(size=(6.0, 6.0), grid_width=0.35, grid_height_range=(0.02, 0.1),
+                                                     platform_width=1.5, holes=True), 0.25),
+        "flat": (mtc.MeshPlaneTerrainCfg(size=(5.0, 4.0)), 0.0),
+    }
+    for k, (name, (cfg, difficulty)) in enumerate(subs.items()):
+        torch.manual_seed(300 + k)
+        res = cfg.function(difficulty, cfg)
+        assert len(res) == 2, (name, type(res), len(res))
+        meshes, origin = res
+        out[name + "_soup"] = soup(cat(meshes))
+        out[name + "_origin"] = np.asarray(origin, np.float64)
+        out[name + "_difficulty"] = np.array([difficulty])
+
+    def rough(num_rows, num_cols, curriculum, seed):
+        return tgc.TerrainGeneratorCfg(
+            size=(8.0, 8.0), border_width=20.0, num_rows=num_rows, num_cols=num_cols, horizontal_scale=0.1, vertical_scale=0.005,
+            slope_threshold=0.75, use_cache=False, curriculum=curriculum, seed=seed,
+            sub_terrains={
+                "pyramid_stairs": mtc.MeshPyramidStairsTerrainCfg(proportion=0.2, step_height_range=(0.05, 0.23), step_width=0.3,
+                                                                  platform_width=3.0, border_width=1.0, holes=False),
+                "pyramid_stairs_inv": mtc.MeshInvertedPyramidStairsTerrainCfg(proportion=0.2, step_height_range=(0.05, 0.23),
+                                                                              step_width=0.3, platform_width=3.0, border_width=1.0, holes=False),
+                "boxes": mtc.MeshRandomGridTerrainCfg(proportion=0.2, grid_width=0.45, grid_height_range=(0.05, 0.2), platform_width=2.0),
+                "random_rough": hfc.HfRandomUniformTerrainCfg(proportion=0.2, noise_range=(0.02, 0.10), noise_step=0.02, border_width=0.25),
+                "hf_pyramid_slope": hfc.HfPyramidSlopedTerrainCfg(proportion=0.1, slope_range=(0.0, 0.4), platform_width=2.0, border_width=0.25),
+                "hf_pyramid_slope_inv": hfc.HfInvertedPyramidSlopedTerrainCfg(proportion=0.1, slope_range=(0.0, 0.4), platform_width=2.0,
+                                                                             border_width=0.25),
+            })
+
+    # reduced layouts, complete soups: curriculum (2 x 10: every sub-terrain type appears) and random (2 x 3)
+    for name, (rows, cols, cur, seed) in {"gen_cur": (2, 10, True, 7), "gen_rand": (2, 3, False, 11)}.items():
+        np.random.seed(seed + 1)
+        torch.manual_seed(seed + 2)
+        g = tg.TerrainGenerator(rough(rows, cols, cur, seed), device="cpu")
+        sp = soup(g.terrain_mesh)
+        # the flat interior of the height-field tiles compresses well; still keep the file small: fp32 soup of a
+        # 2 x 10 layout is ~4.6 MB raw
+        out[name + "_soup"] = sp
+        out[name + "_origins"] = np.asarray(g.terrain_origins, np.float64)
+        out[name + "_layout"] = np.array([rows, cols, int(cur), seed])
+    # the benchmark terrain itself (ROUGH_TERRAINS_CFG, curriculum on as velocity_env_cfg.py:314-318 sets it, seed 42):
+    # digest of the fp32 soup, its size, every 4099th triangle, the tile origins
+    np.random.seed(42)
+    torch.manual_seed(42)
+    g = tg.TerrainGenerator(rough(10, 20, True, 42), device="cpu")
+    sp = soup(g.terrain_mesh)
+    out["rough_digest"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(sp).tobytes()).digest(), dtype=np.uint8).copy()
+    out["rough_num_tris"] = np.array([sp.shape[0]])
+    out["rough_sample"] = sp[::4099].copy()
+    out["rough_origins"] = np.asarray(g.terrain_origins, np.float64)
+    # env-origin layout of TerrainImporter (terrain_importer.py:328-349) on those origins
+    ti = R.ref_import("isaaclab.terrains.terrain_importer")
+    imp = _NS(cfg=_NS(max_init_terrain_level=5), device="cpu")
+    torch.manual_seed(43)
+    eo = ti.TerrainImporter._compute_env_origins_curriculum(imp, 4096, torch.from_numpy(g.terrain_origins).to(dtype=torch.float))
+    out.update(rough_env_origins=eo, rough_levels=imp.terrain_levels, rough_types=imp.terrain_types)
+    save("mesh_terrains", **out)
+
+
 def gen_samplers():
     """Samplers of utils/math.py:1233-1421 run by the REFERENCE functions on recorded draws: torch.rand / torch.randn
     hand out prepared tensors while they run (for the scripted ones the module is loaded a second time with
@@ -1294,10 +1388,10 @@ def gen_samplers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera", "samplers"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera", "samplers", "mesh_terrains"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
              "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
-             "events": gen_events, "terrains": gen_terrains, "imu": gen_imu,
+             "events": gen_events, "terrains": gen_terrains, "mesh_terrains": gen_mesh_terrains, "imu": gen_imu,
              "frames": gen_frame_transformer, "camera": gen_camera, "samplers": gen_samplers}
     for w in which:
         table[w]()

@@ -156,7 +156,7 @@ def test_post_physics_step_rejects_what_it_does_not_cover(device):
 
     from isaaclab_amd import _lib as L
 
-    env, rec, outs = run_env("anymal_d_rough", 16, 3, device, seed=21, small_terrain=True, persistent=True)
+    env, rec, outs = run_env("anymal_d_rough", 16, 3, device, seed=21, small_terrain=True, persistent=True, mesh_accel="bvh")
     assert env.mesh.info()["accel"] == "bvh" and getattr(env, "_single_launch_steps", 0) == 0
     env._mesh_has_grid = lambda mesh: True          # skip the host-side check: the C entry point must refuse itself
     with pytest.raises(NotImplementedError, match="vertical-ray"):

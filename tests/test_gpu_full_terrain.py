@@ -1,5 +1,6 @@
-"""The benchmark's ray-cast target at its real size: the ~1.16 M-triangle rough terrain (80 sub-terrain tiles + border,
-~2.4 M grid cells) that ``bench.py`` casts against, which the other tests only cover in its 2 x 5-tile variant.
+"""The benchmark's ray-cast target at its real size: ROUGH_TERRAINS_CFG through the restated TerrainGenerator (200 tiles
+of 8 m + 20 m border, ~1.19 M triangles, identical to the reference generator's output: tests/test_terrain_generator.py)
+that ``bench.py`` casts against, which the other tests only cover in its 2 x 10-tile variant.
 
 S4 has no reference vectors (warp-lang is absent, SURVEY.md 8c: parity unpinned by the reference), so the answer is
 defined by ``oracle/raycast_ref.c`` -- a self-contained restatement of the published watertight test that shares no
@@ -39,11 +40,11 @@ def _moller_trumbore_f64(tri, s, d):
 
 @pytest.fixture(scope="module")
 def full_terrain(device):
-    from isaaclab_amd.terrains import SyntheticTerrain, SyntheticTerrainCfg
+    from isaaclab_amd.envs.synthetic import make_rough_terrain
     from isaaclab_amd.utils.warp import convert_to_warp_mesh
 
     n = 4096
-    terrain = SyntheticTerrain(SyntheticTerrainCfg(), n)          # 10 x 20 tiles of 8 m + 20 m border: bench.py's mesh
+    terrain = make_rough_terrain(n)                               # 10 x 20 tiles of 8 m + 20 m border: bench.py's mesh
     assert terrain.triangles.shape[0] > 1_000_000
     mesh = convert_to_warp_mesh(terrain.vertices, terrain.triangles, str(device), accel="grid")
     info = mesh.info()
