@@ -138,6 +138,10 @@ def _trace(rank, msg):
 
 def main():
     args = parse()
+    if os.environ.get("MDP_BENCH_WATCHDOG"):       # diagnosis of a stalled rehearsal: dump every thread's stack and leave
+        import faulthandler
+
+        faulthandler.dump_traceback_later(int(os.environ["MDP_BENCH_WATCHDOG"]), exit=True)
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))

@@ -13,6 +13,8 @@ here is plumbing around ``torch.distributed`` (backend "nccl" = RCCL on ROCm; "g
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -146,9 +148,14 @@ def allreduce_payload(payload: torch.Tensor, world: int, group=None):
     """One asynchronous all-reduce(sum) of the packed ``[sum, count]`` vector; returns the work handle (None when
     there is a single rank)."""
     if world > 1:
-        if payload.is_cuda and dist.get_backend(group) == "gloo":
-            # gloo is the CPU transport (tests, one-box rehearsals): its device-tensor path never completes next to
-            # hipGraph replays on this stack, so stage through the host -- RCCL ("nccl") takes the branch below
+        if payload.is_cuda and dist.get_backend(group) == "gloo" and os.environ.get("MDP_GLOO_DEVICE_PATH") != "1":
+            # gloo is the CPU transport (tests, one-box rehearsals).  Its device-tensor path (ProcessGroupGloo stages the
+            # tensor through pinned host memory on a pool stream and synchronises that stream from its worker thread
+            # while this thread blocks in Work.wait()) stalls in the two-rank one-GPU rehearsal: round-2 diagnosis
+            # (tools/rehearse_two_ranks.sh, MDP_GLOO_DEVICE_PATH=1 + watchdog) -- the first timed region passes, in the
+            # second both ranks sit in Work.wait() of the same collective for good; with the payload staged through the
+            # host by this thread the same rehearsal completes.  The stall is inside gloo's staging, which the RCCL
+            # branch below never enters (one collective kernel on RCCL's stream, Work.wait() = a device-side event wait).
             host = payload.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
             payload.copy_(host)

@@ -1,2 +1,2 @@
-from .patterns import grid_pattern
-from .patterns_cfg import GridPatternCfg, PatternBaseCfg
+from .patterns import grid_pattern, pinhole_camera_pattern
+from .patterns_cfg import GridPatternCfg, PatternBaseCfg, PinholeCameraPatternCfg

@@ -1215,6 +1215,92 @@ def gen_camera():
     save("camera", **out)
 
 
+def gen_camera_class():
+    """RayCasterCamera as a class (ray_caster_camera.py:121-255, 370-430), the pinhole pattern (patterns.py:61-104,
+    patterns_cfg.py:120-172) and the camera-convention helpers (math.py:1429-1561), all run by the REFERENCE code: rays of
+    a pinhole cfg with aperture offsets, intrinsics, the offsets `set_world_poses` / `set_world_poses_from_view` compute,
+    and one update after them (raycast_mesh served by the CPU ray-cast oracle, as in gen_camera)."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from isaaclab_amd.terrains import height_field as HF
+    from oracle.raycast_np import GridCaster, tri_soup
+
+    m = R.ref_math()
+    cam = R.ref_import("isaaclab.sensors.ray_caster.ray_caster_camera")
+    pat = R.ref_import("isaaclab.sensors.ray_caster.patterns.patterns")
+    pcfg = R.ref_import("isaaclab.sensors.ray_caster.patterns.patterns_cfg")
+    g = torch.Generator().manual_seed(77)
+    out = {}
+    # -- conventions
+    q = rand_quat(g, 7)
+    out["conv_q"] = q
+    for origin in ("opengl", "ros", "world"):
+        for target in ("opengl", "ros", "world"):
+            out[f"conv_{origin}_{target}"] = m.convert_camera_frame_orientation_convention(q.clone(), origin=origin, target=target)
+    eyes = torch.randn(6, 3, generator=g) * 2.0
+    targets = torch.randn(6, 3, generator=g)
+    targets[0] = eyes[0] + torch.tensor([0.0, 0.0, -1.5])          # straight down: the degenerate x-axis branch
+    out.update(view_eyes=eyes, view_targets=targets)
+    out["view_rot_Z"] = m.create_rotation_matrix_from_view(eyes, targets, up_axis="Z")
+    out["view_rot_Y"] = m.create_rotation_matrix_from_view(eyes, targets, up_axis="Y")
+    # -- pattern cfg from an intrinsic matrix, intrinsics, rays
+    K = [38.0, 0.0, 4.3, 0.0, 35.0, 2.6, 0.0, 0.0, 1.0]
+    pc = pcfg.PinholeCameraPatternCfg.from_intrinsic_matrix(K, width=8, height=6, focal_length=12.0)
+    out["pc_fields"] = np.array([pc.focal_length, pc.horizontal_aperture, pc.vertical_aperture, pc.horizontal_aperture_offset,
+                                 pc.vertical_aperture_offset, pc.width, pc.height], np.float64)
+    # -- the class
+    np.random.seed(5)
+    meshes, _ = HF.pyramid_stairs_terrain(0.8, HF.HfPyramidStairsTerrainCfg(size=(6.0, 6.0), border_width=0.5, slope_threshold=0.75,
+                                                                             platform_width=1.5))
+    verts, faces = meshes[0].vertices, meshes[0].faces
+    caster = GridCaster(tri_soup(verts, faces))
+
+    def raycast_mesh(starts, dirs, mesh=None, max_dist=1e6, return_distance=False, return_normal=False, **kw):
+        shape = starts.shape[:-1]
+        hits, dist, normal, _ = caster.cast(starts.reshape(-1, 3).numpy(), dirs.reshape(-1, 3).numpy(), max_dist)
+        return (torch.from_numpy(hits).reshape(*shape, 3), torch.from_numpy(dist).reshape(*shape) if return_distance else None,
+                torch.from_numpy(normal).reshape(*shape, 3) if return_normal else None, None)
+
+    cam.raycast_mesh = raycast_mesh
+    cam.stage_utils = _NS(get_stage_up_axis=lambda: "Z")
+    n = 5
+    view_pose = torch.cat([torch.tensor([3.0, 3.0, 2.0]) + torch.randn(n, 3, generator=g) * 0.4, rand_quat(g, n)], dim=1)   # wxyz
+    s = cam.RayCasterCamera.__new__(cam.RayCasterCamera)
+    for name in ("_initialize_handle", "_invalidate_initialize_handle", "_prim_deletion_callback_id", "_debug_vis_handle"):
+        setattr(s, name, None)
+    s._device = "cpu"
+    s._view = _NS(count=n)
+    s._data = cam.CameraData()
+    s.cfg = _NS(mesh_prim_paths=["/m"], data_types=["distance_to_image_plane", "distance_to_camera", "normals"],
+                depth_clipping_behavior="max", max_distance=4.0, pattern_cfg=pc,
+                offset=_NS(pos=(0.1, -0.05, 0.2), rot=(0.9238795, 0.0, 0.3826834, 0.0), convention="ros"))
+    s._compute_view_world_poses = lambda env_ids: (view_pose[env_ids, :3].clone(), view_pose[env_ids, 3:].clone())
+    s.meshes = {"/m": None}
+    s._initialize_rays_impl()
+    out.update(vertices=verts, faces=faces.astype(np.int32), cls_view_pose=view_pose,
+               cls_intrinsics=s._data.intrinsic_matrices.clone(), cls_ray_starts=s.ray_starts.clone(),
+               cls_ray_directions=s.ray_directions.clone(), cls_offset_pos0=s._offset_pos.clone(), cls_offset_quat0=s._offset_quat.clone())
+    # configuration calls: world pose in the ros convention for envs 0..2, look-at for envs 3..4
+    set_pos = torch.tensor([3.0, 3.0, 2.6]) + torch.randn(3, 3, generator=g) * 0.3
+    set_quat = rand_quat(g, 3)
+    s.set_world_poses(set_pos, set_quat, env_ids=torch.tensor([0, 1, 2]), convention="ros")
+    eyes2 = torch.tensor([[2.0, 2.5, 2.8], [4.0, 3.5, 2.4]])
+    targets2 = torch.tensor([[3.0, 3.0, 0.3], [3.0, 3.0, 0.5]])
+    s.set_world_poses_from_view(eyes2, targets2, env_ids=torch.tensor([3, 4]))
+    out.update(cls_set_pos=set_pos, cls_set_quat=set_quat, cls_eyes=eyes2, cls_targets=targets2,
+               cls_offset_pos=s._offset_pos.clone(), cls_offset_quat=s._offset_quat.clone(),
+               cls_pos_w_cfg=s._data.pos_w.clone(), cls_quat_w_cfg=s._data.quat_w_world.clone())
+    # new intrinsics for two envs
+    K2 = torch.tensor([[[30.0, 0.0, 4.0], [0.0, 31.0, 3.0], [0.0, 0.0, 1.0]]]).repeat(2, 1, 1)
+    s.set_intrinsic_matrices(K2, focal_length=2.0, env_ids=torch.tensor([1, 4]))
+    out.update(cls_K2=K2, cls_ray_directions2=s.ray_directions.clone())
+    s._frame = torch.zeros(n, dtype=torch.long)
+    s._update_buffers_impl(torch.arange(n))
+    out.update(cls_pos_w=s._data.pos_w.clone(), cls_quat_w=s._data.quat_w_world.clone(), cls_hits=s.ray_hits_w.clone(),
+               cls_image_plane=s._data.output["distance_to_image_plane"].clone(),
+               cls_camera=s._data.output["distance_to_camera"].clone(), cls_normals=s._data.output["normals"].clone())
+    save("camera_class", **out)
+
+
 def gen_terrains():
     """Height-field sub-terrains by the reference (hf_terrains.py + height_field/utils.py), trimesh.Trimesh replaced by a
     recorder of (vertices, faces); np.random seeded before the random terrain."""
@@ -1388,10 +1474,10 @@ def gen_samplers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera", "samplers", "mesh_terrains"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera", "samplers", "camera_class", "mesh_terrains"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
              "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
              "events": gen_events, "terrains": gen_terrains, "mesh_terrains": gen_mesh_terrains, "imu": gen_imu,
-             "frames": gen_frame_transformer, "camera": gen_camera, "samplers": gen_samplers}
+             "frames": gen_frame_transformer, "camera": gen_camera, "camera_class": gen_camera_class, "samplers": gen_samplers}
     for w in which:
         table[w]()
