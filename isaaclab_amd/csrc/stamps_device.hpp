@@ -10,7 +10,11 @@ static __device__ unsigned long long* g_stamps = nullptr;   // [blocks][8], one 
 __device__ __forceinline__ void stamp(int slot, unsigned long long tag = 0) {
     if (g_stamps && threadIdx.x == 0) {
         g_stamps[(size_t)blockIdx.x * 8 + slot] = wall_clock64();
-        if (slot == 0) g_stamps[(size_t)blockIdx.x * 8 + 7] = tag;
+        // tag | HW_ID (wave / simd / cu / sh / se ids) << 8 | XCC_ID << 40: where the block ran
+        if (slot == 0)
+            g_stamps[(size_t)blockIdx.x * 8 + 7] =
+                tag | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8) |
+                ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) << 40);
     }
 }
 }  // namespace mdp

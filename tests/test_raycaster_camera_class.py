@@ -91,7 +91,7 @@ def test_gpu_camera_class_flow(device, accel):
                              offset=RayCasterCameraCfg.OffsetCfg(pos=(0.1, -0.05, 0.2), rot=(0.9238795, 0.0, 0.3826834, 0.0), convention="ros"))
     cam = RayCasterCamera(cfg, View(), mesh, n, str(device), 0.005)
     t = lambda x: x.detach().cpu().numpy()
-    assert cam.image_shape == (6, 8) and cam.num_rays == 48 and cam.data.image_shape == (6, 8)
+    assert cam.image_shape == (6, 8) and cam.num_rays == 48 and cam._data.image_shape == (6, 8)
     np.testing.assert_allclose(t(cam._data.intrinsic_matrices), G["cls_intrinsics"], **TOL)
     np.testing.assert_allclose(t(cam.ray_directions), G["cls_ray_directions"], **TOL)
     np.testing.assert_allclose(t(cam._offset_pos), G["cls_offset_pos0"], **TOL)
@@ -133,5 +133,14 @@ def test_gpu_camera_class_flow(device, accel):
     assert t(cam.frame).tolist() == [0] * n and cam._is_outdated.all()
     cam.update(0.005, force_recompute=True)
     assert t(cam.frame).tolist() == [1] * n
+    # a sensor with an update period only recomputes once the period has passed (sensor_base.py:197-205)
+    cam.cfg.update_period = 0.02
+    cam.update(0.005)
+    cam.data
+    assert t(cam.frame).tolist() == [1] * n
+    for _ in range(4):
+        cam.update(0.005)
+    cam.data
+    assert t(cam.frame).tolist() == [2] * n
     # the quaternion in the other conventions (CameraData.quat_w_ros / quat_w_opengl)
     np.testing.assert_allclose(np.abs((t(data.quat_w_ros) * cm.convert_camera_frame_orientation_convention(G["cls_quat_w"], "world", "ros")).sum(-1)), 1.0, atol=1e-5)

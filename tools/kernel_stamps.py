@@ -22,7 +22,9 @@ from isaaclab_amd.envs.synthetic import make_velocity_env
 def show(name, st, roles, phases):
     st = st.cpu().numpy().astype(np.int64)
     used = st[:, 0] != 0
-    st = st[used]
+    st = st[used].copy()
+    hw = st[:, 7] >> 8
+    st[:, 7] &= 0xFF
     t0 = st[:, 0].min()
     print(f"== {name}: {used.sum()} blocks, launch span {(st[:, 1:6].max() - t0) / 100.0:.2f} us")
     for tag, rname in roles.items():
@@ -38,11 +40,27 @@ def show(name, st, roles, phases):
         if last > 1:
             d = np.diff(rel, axis=1)
             print("           phase medians (us): " + "  ".join(f"{np.median(d[:, k]):.2f}" for k in range(d.shape[1])))
+    # residency: blocks alive at a few instants, and how the blocks spread over the XCDs / CUs (HW_ID, XCC_ID)
+    end = st[:, 1:6].max(axis=1)
+    ts = np.linspace(t0, end.max(), 12)[1:-1]
+    print("  blocks alive at t (us): " + "  ".join(f"{(t - t0) / 100.0:.1f}:{int(((st[:, 0] <= t) & (end > t)).sum())}" for t in ts))
+    xcc, cu, sh, se = (hw >> 32) & 0xF, (hw >> 8) & 0xF, (hw >> 12) & 1, (hw >> 13) & 7
+    cuid = ((xcc * 8 + se) * 2 + sh) * 16 + cu
+    per_cu = np.bincount(cuid)
+    per_cu = per_cu[per_cu > 0]
+    print(f"  distinct CUs {len(per_cu)}  blocks per CU min/med/max {per_cu.min()}/{int(np.median(per_cu))}/{per_cu.max()}  per XCC {np.bincount(xcc).tolist()}")
+    alive_cu = []
+    for t in ts[::3]:
+        a = (st[:, 0] <= t) & (end > t)
+        c = np.bincount(cuid[a], minlength=cuid.max() + 1)
+        alive_cu.append(f"{(t - t0) / 100.0:.1f}: max {c.max()} mean {c[np.unique(cuid)].mean():.2f}")
+    print("  blocks alive per CU at t: " + " | ".join(alive_cu))
 
 
 def cast_phases(st):
     """cast blocks: slots 0 start, 2 flags known (two barriers), 3 pose + yaw quaternion, 4 cell walk done, 1 end"""
     st = st.cpu().numpy().astype(np.int64)
+    st[:, 7] &= 0xFF
     r = st[(st[:, 0] != 0) & (st[:, 7] == 1)]
     seq = r[:, [0, 2, 3, 4, 1]] / 100.0
     d = np.diff(seq, axis=1)
@@ -83,6 +101,7 @@ def main():
             show("k_post_physics", buf, {2: "managers", 1: "cast"}, {2: 5, 1: 1})
             if reset:
                 st = buf.cpu().numpy().astype(np.int64)
+                st[:, 7] &= 0xFF
                 m = st[(st[:, 0] != 0) & (st[:, 7] == 2)]
                 last = m[np.argmax(m[:, 5])]
                 t0 = st[st[:, 0] != 0][:, 0].min()
