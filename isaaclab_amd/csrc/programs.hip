@@ -911,8 +911,11 @@ struct PostArgs {
 #ifndef MDP_POST_MIN_WAVES
 #define MDP_POST_MIN_WAVES 6
 #endif
+#ifndef MDP_POST_MAX_THREADS
+#define MDP_POST_MAX_THREADS 768
+#endif
 template <int BATCH, bool RESET>
-__global__ void __launch_bounds__(256, MDP_POST_MIN_WAVES) k_post_physics(PostArgs a) {
+__global__ void __launch_bounds__(MDP_POST_MAX_THREADS, MDP_POST_MIN_WAVES) k_post_physics(PostArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
         MDP_STAMP(0, 1);
@@ -1452,7 +1455,7 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
     static const int threads_env = [] {
         const char* v = std::getenv("MDP_POST_THREADS");
         int t = v ? std::atoi(v) : 0;      // 0: whole waves covering one cast slot group (<= 256 threads)
-        return t <= 0 ? 0 : (t < 64 ? 64 : (t > 256 ? 256 : (t / 64) * 64));   // the kernel is built for <= 256 threads
+        return t <= 0 ? 0 : (t < 64 ? 64 : (t > MDP_POST_MAX_THREADS ? MDP_POST_MAX_THREADS : (t / 64) * 64));
     }();
     static const int post_envs = [] {
         const char* v = std::getenv("MDP_POST_ENVS");
