@@ -14,4 +14,5 @@ for c in "TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CY
   timeout -s KILL 120 rocprofv3 --pmc $c -d $P/p$i -o p$i -- python3 tools/prof_cast.py > $P/p$i.log 2>&1
   python3 tools/rocprof_pmc.py $(find $P/p$i -name "*_results.db" | head -1) 2>&1 | grep -E "k_raycaster_update_down|k_post_physics" >> $P/summary.txt
 done
+find $P -name "*.db" -delete
 cat $P/summary.txt
