@@ -12,7 +12,10 @@ __device__ __forceinline__ void velocity_command_env(
     float* __restrict__ heading_target, uint8_t* __restrict__ is_heading, uint8_t* __restrict__ is_standing,
     float* __restrict__ time_left, int64_t* __restrict__ counter, float* __restrict__ m_xy,
     float* __restrict__ m_yaw, float dt, uint64_t seed, uint64_t epoch, const float* __restrict__ inj,
-    const uint8_t* __restrict__ force) {
+    const uint8_t* __restrict__ force, float* defer = nullptr) {
+    // defer != nullptr (compute path only): the new command goes to defer[0..2] instead of cmd -- the caller stores it
+    // once nobody reads the previous command any more (the post-physics kernel evaluates the command update next to
+    // the termination terms, ahead of the rewards, which read the previous command); every other buffer is written here
     const float* r = st + (int64_t)e * ld;
     Q4 q = ld4(r + 3);
     float c0 = cmd[3 * e + 0], c1 = cmd[3 * e + 1], c2 = cmd[3 * e + 2];
@@ -82,6 +85,10 @@ __device__ __forceinline__ void velocity_command_env(
         c0 = 0.0f;
         c1 = 0.0f;
         c2 = 0.0f;
+    }
+    if (defer) {
+        defer[0] = c0; defer[1] = c1; defer[2] = c2;
+        return;
     }
     cmd[3 * e + 0] = c0;
     cmd[3 * e + 1] = c1;

@@ -21,7 +21,8 @@ MDP_DEV float rotation_distance(Q4 obj, Q4 target) {
 // :97-117, one thread per (env, actuated joint)
 __global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ actions,
                                const int32_t* __restrict__ act_idx, const float* __restrict__ lower,
-                               const float* __restrict__ upper, float* __restrict__ cur, float* __restrict__ prev) {
+                               const float* __restrict__ upper, float* __restrict__ cur, float* __restrict__ prev,
+                               float* __restrict__ target, int ld_target) {
     int64_t total = (int64_t)cfg.num_envs * cfg.num_actuated;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -35,6 +36,8 @@ __global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ a
         t = tmax(tmin(t, hi), lo);  // math.py:64-78 saturate
         cur[o] = t;
         prev[o] = t;
+        // set_joint_position_target(cur_targets[:, actuated], joint_ids=actuated) (:115-117, articulation.py:807-830)
+        if (target) target[e * ld_target + j] = t;
     }
 }
 
@@ -42,9 +45,11 @@ __global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ a
 __global__ void k_dones(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, const float* __restrict__ origins,
                         const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
                         const float* __restrict__ successes, int64_t* __restrict__ ep_len,
-                        uint8_t* __restrict__ out_of_reach, uint8_t* __restrict__ time_out) {
+                        uint8_t* __restrict__ out_of_reach, uint8_t* __restrict__ time_out, int increment,
+                        uint8_t* __restrict__ reset_buf) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.num_envs) return;
+    if (increment) ep_len[e] += 1;          // direct_rl_env.py:343 episode_length_buf += 1, ahead of _get_dones
     const float* r = obj + 13 * (int64_t)e;
     V3 pos{r[0] - origins[3 * e], r[1] - origins[3 * e + 1], r[2] - origins[3 * e + 2]};
     V3 d{pos.x - in_hand[3 * e], pos.y - in_hand[3 * e + 1], pos.z - in_hand[3 * e + 2]};
@@ -59,6 +64,7 @@ __global__ void k_dones(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, con
     }
     bool to = len >= cfg.max_episode_length - 1;
     time_out[e] = (to || max_succ) ? 1 : 0;
+    if (reset_buf) reset_buf[e] = (goal_dist >= cfg.fall_dist || to || max_succ) ? 1 : 0;   // direct_rl_env.py:346
 }
 
 // :377-433 per-env part; cross-env sums accumulated per block then atomically in fp64
@@ -106,12 +112,13 @@ __global__ void k_rewards(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, c
 }
 
 __global__ void k_finish_rewards(mdp_inhand_cfg_t cfg, const double* __restrict__ partials,
-                                 float* __restrict__ cons) {
+                                 float* __restrict__ cons, double* __restrict__ rezero) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         float num_resets = (float)partials[0];
         float finished = (float)partials[1];
         if (num_resets > 0.0f)
             cons[0] = cfg.av_factor * finished / num_resets + (1.0f - cfg.av_factor) * cons[0];
+        if (rezero) { rezero[0] = 0.0; rezero[1] = 0.0; }
     }
 }
 
@@ -121,7 +128,8 @@ __global__ void k_full_obs(mdp_inhand_cfg_t cfg, const float* __restrict__ q, co
                            const float* __restrict__ obj, const float* __restrict__ origins,
                            const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
                            const float* __restrict__ body, const int32_t* __restrict__ fingers,
-                           const float* __restrict__ actions, int A, float* __restrict__ obs, int ld_obs, int O) {
+                           const float* __restrict__ actions, int A, float* __restrict__ obs, int ld_obs, int O,
+                           const float* __restrict__ link_xf, const float* __restrict__ link_vel) {
     int D = cfg.num_dofs, F = cfg.num_fingertips, B = cfg.num_bodies;
     int64_t total = (int64_t)cfg.num_envs * O;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
@@ -151,13 +159,16 @@ __global__ void k_full_obs(mdp_inhand_cfg_t cfg, const float* __restrict__ q, co
             v = get(quat_mul(ld4(r + 3), quat_conjugate(ld4(goal_rot + 4 * e))), k);
         } else if ((k -= 4) < 3 * F) {
             int f = k / 3, a = k - 3 * f;
-            v = body[(e * B + fingers[f]) * 13 + a] - origins[3 * e + a];
+            // body == nullptr: the fingertip rows come from the physics view's link buffers (xyzw transforms, (N,B,7) and
+            // (N,B,6)) -- the values body_state_w would hold (articulation_data.py:323-337) without packing all B bodies
+            float p = body ? body[(e * B + fingers[f]) * 13 + a] : link_xf[(e * B + fingers[f]) * 7 + a];
+            v = p - origins[3 * e + a];
         } else if ((k -= 3 * F) < 4 * F) {
             int f = k / 4, a = k - 4 * f;
-            v = body[(e * B + fingers[f]) * 13 + 3 + a];
+            v = body ? body[(e * B + fingers[f]) * 13 + 3 + a] : link_xf[(e * B + fingers[f]) * 7 + (a == 0 ? 6 : 2 + a)];
         } else if ((k -= 4 * F) < 6 * F) {
             int f = k / 6, a = k - 6 * f;
-            v = body[(e * B + fingers[f]) * 13 + 7 + a];
+            v = body ? body[(e * B + fingers[f]) * 13 + 7 + a] : link_vel[(e * B + fingers[f]) * 6 + a];
         } else {
             k -= 6 * F;
             v = actions[e * A + k];
@@ -175,7 +186,22 @@ extern "C" int mdp_inhand_apply_action(const mdp_inhand_cfg_t* cfg, const float*
     int64_t total = (int64_t)cfg->num_envs * cfg->num_actuated;
     if (total == 0) return MDP_OK;
     hipLaunchKernelGGL(k_apply_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, actions,
-                       actuated_idx, lower, upper, cur_targets, prev_targets);
+                       actuated_idx, lower, upper, cur_targets, prev_targets, (float*)nullptr, 0);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const float* actions,
+                                          const int32_t* actuated_idx, const float* lower, const float* upper,
+                                          float* cur_targets, float* prev_targets, float* joint_pos_target,
+                                          int ld_target, void* stream) {
+    MDP_REQUIRE(cfg && actions && actuated_idx && lower && upper && cur_targets && prev_targets && joint_pos_target,
+                "null pointer");
+    MDP_REQUIRE(ld_target >= cfg->num_dofs, "joint_pos_target row stride %d < %d dofs", ld_target, cfg->num_dofs);
+    int64_t total = (int64_t)cfg->num_envs * cfg->num_actuated;
+    if (total == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_apply_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, actions,
+                       actuated_idx, lower, upper, cur_targets, prev_targets, joint_pos_target, ld_target);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
@@ -189,7 +215,22 @@ extern "C" int mdp_inhand_dones(const mdp_inhand_cfg_t* cfg, const float* object
     if (cfg->num_envs == 0) return MDP_OK;
     hipLaunchKernelGGL(k_dones, dim3(grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), *cfg,
                        object_root_state, env_origins, in_hand_pos, goal_rot, successes, episode_length_buf,
-                       out_of_reach, time_out);
+                       out_of_reach, time_out, 0, (uint8_t*)nullptr);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, const float* object_root_state,
+                                     const float* env_origins, const float* in_hand_pos, const float* goal_rot,
+                                     const float* successes, int64_t* episode_length_buf, uint8_t* reset_terminated,
+                                     uint8_t* reset_time_outs, uint8_t* reset_buf, void* stream) {
+    MDP_REQUIRE(cfg && object_root_state && env_origins && in_hand_pos && goal_rot && successes &&
+                    episode_length_buf && reset_terminated && reset_time_outs && reset_buf,
+                "null pointer");
+    if (cfg->num_envs == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_dones, dim3(grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), *cfg,
+                       object_root_state, env_origins, in_hand_pos, goal_rot, successes, episode_length_buf,
+                       reset_terminated, reset_time_outs, 1, reset_buf);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
@@ -216,7 +257,33 @@ extern "C" int mdp_inhand_finish_rewards(const mdp_inhand_cfg_t* cfg, const doub
                                          float* consecutive_successes, void* stream) {
     MDP_REQUIRE(cfg && partials && consecutive_successes, "null pointer");
     hipLaunchKernelGGL(k_finish_rewards, dim3(1), dim3(64), 0, as_stream(stream), *cfg, partials,
-                       consecutive_successes);
+                       consecutive_successes, (double*)nullptr);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_rewards_step(const mdp_inhand_cfg_t* cfg, const float* object_root_state,
+                                       const float* env_origins, const float* in_hand_pos, const float* goal_rot,
+                                       const float* actions, const uint8_t* reset_buf, uint8_t* reset_goal_buf,
+                                       float* successes, float* reward, double* partials, void* stream) {
+    MDP_REQUIRE(cfg && object_root_state && env_origins && in_hand_pos && goal_rot && actions && reset_buf &&
+                    reset_goal_buf && successes && reward && partials,
+                "null pointer");
+    if (cfg->num_envs == 0) return MDP_OK;
+    // reset_goal_buf is read and written by the same thread of the same env: updated in place.  `partials` is zero on
+    // entry: zero-initialised by its owner, left zeroed by mdp_inhand_finish_rewards_step of the step before
+    hipLaunchKernelGGL(k_rewards, dim3(grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), *cfg,
+                       object_root_state, env_origins, in_hand_pos, goal_rot, actions, reset_buf, reset_goal_buf,
+                       successes, reward, reset_goal_buf, partials);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_finish_rewards_step(const mdp_inhand_cfg_t* cfg, double* partials,
+                                              float* consecutive_successes, void* stream) {
+    MDP_REQUIRE(cfg && partials && consecutive_successes, "null pointer");
+    hipLaunchKernelGGL(k_finish_rewards, dim3(1), dim3(64), 0, as_stream(stream), *cfg, partials,
+                       consecutive_successes, partials);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
@@ -235,7 +302,28 @@ extern "C" int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joi
     if (total == 0) return MDP_OK;
     hipLaunchKernelGGL(k_full_obs, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, joint_pos,
                        joint_vel, lower, upper, object_root_state, env_origins, in_hand_pos, goal_rot, body_state_w,
-                       finger_bodies, actions, action_dim, obs, ld_obs, O);
+                       finger_bodies, actions, action_dim, obs, ld_obs, O, (const float*)nullptr, (const float*)nullptr);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_full_obs_from_view(const mdp_inhand_cfg_t* cfg, const float* joint_pos, const float* joint_vel,
+                                             const float* lower, const float* upper, const float* object_root_state,
+                                             const float* env_origins, const float* in_hand_pos, const float* goal_rot,
+                                             const float* link_transforms, const float* link_velocities,
+                                             const int32_t* finger_bodies, const float* actions, int action_dim,
+                                             float* obs, int ld_obs, void* stream) {
+    MDP_REQUIRE(cfg && joint_pos && joint_vel && lower && upper && object_root_state && env_origins && in_hand_pos &&
+                    goal_rot && link_transforms && link_velocities && finger_bodies && actions && obs,
+                "null pointer");
+    int O = 2 * cfg->num_dofs + 13 + 11 + 13 * cfg->num_fingertips + action_dim;
+    MDP_REQUIRE(ld_obs >= O, "obs buffer too narrow (%d < %d)", ld_obs, O);
+    int64_t total = (int64_t)cfg->num_envs * O;
+    if (total == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_full_obs, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, joint_pos,
+                       joint_vel, lower, upper, object_root_state, env_origins, in_hand_pos, goal_rot,
+                       (const float*)nullptr, finger_bodies, actions, action_dim, obs, ld_obs, O, link_transforms,
+                       link_velocities);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -972,6 +972,26 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, MDP_POST_MIN_WAVES) k_po
     __threadfence_block();
     __syncthreads();
     // ---- terminations (termination_manager.py:151-174): wave w evaluates terms w, w + nwaves, ...
+    // Without the reset branch the command update (command_manager.py:151-187) is evaluated HERE, by the last wave, next
+    // to the termination terms -- it needs the updated root state and nothing the terminations or rewards produce --
+    // and only its result, the new command, is held back in registers until the rewards have read the previous one
+    // (stored where the command phase used to be).  One dependent phase less in the block's chain.
+    __shared__ float s_cmd[3][64];      // the new command of the block's envs until the rewards are through
+    const bool cmd_early = !RESET && a.has_cmd;
+    if (cmd_early && wave == nwaves - 1) {
+        uint64_t seed = 0, epoch = 0;
+        const bool gen = a.cmd.rng_state != nullptr && a.cmd.injected_u == nullptr;
+        if (a.cmd.rng_state) { seed = a.cmd.rng_state[0]; epoch = a.cmd.rng_state[4 + b]; }
+        if (e < N) {
+            float cmd_new[3];
+            velocity_command_env(a.cmd.cfg, e, a.cmd.root_state, a.cmd.ld_state, a.cmd.vel_command_b, a.cmd.heading_target,
+                                 a.cmd.is_heading_env, a.cmd.is_standing_env, a.cmd.time_left, a.cmd.command_counter,
+                                 a.cmd.metric_error_vel_xy, a.cmd.metric_error_vel_yaw, a.cmd.dt, seed, epoch | (1ull << 62),
+                                 a.cmd.injected_u, nullptr, cmd_new);
+            s_cmd[0][lane] = cmd_new[0]; s_cmd[1][lane] = cmd_new[1]; s_cmd[2][lane] = cmd_new[2];
+        }
+        if (gen && lane == 0) a.cmd.rng_state[4 + b] = epoch + 1;
+    }
     for (int ti = wave; ti < a.Tt; ti += nwaves) {
         const mdp_term_t& t = tterms[ti];
         bool v = e < N ? term_value(t, a.tpool, e) : false;
@@ -1093,7 +1113,15 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, MDP_POST_MIN_WAVES) k_po
     // rewards, which read the previous command
     __syncthreads();
     MDP_STAMP(3);
-    if (a.has_cmd) {
+    if (cmd_early) {
+        if (wave == nwaves - 1 && e < N) {
+            a.cmd.vel_command_b[3 * e + 0] = s_cmd[0][lane];
+            a.cmd.vel_command_b[3 * e + 1] = s_cmd[1][lane];
+            a.cmd.vel_command_b[3 * e + 2] = s_cmd[2][lane];
+        }
+        __threadfence_block();
+        __syncthreads();
+    } else if (RESET && a.has_cmd) {
         uint64_t seed = 0, epoch = 0;
         const bool gen = a.cmd.rng_state != nullptr && a.cmd.injected_u == nullptr;
         if (a.cmd.rng_state) { seed = a.cmd.rng_state[0]; epoch = a.cmd.rng_state[4 + b]; }
@@ -1457,11 +1485,16 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         int t = v ? std::atoi(v) : 0;      // 0: whole waves covering one cast slot group (<= 256 threads)
         return t <= 0 ? 0 : (t < 64 ? 64 : (t > MDP_POST_MAX_THREADS ? MDP_POST_MAX_THREADS : (t / 64) * 64));
     }();
-    static const int post_envs = [] {
+    static const int post_envs_forced = [] {
         const char* v = std::getenv("MDP_POST_ENVS");
-        int e = v ? std::atoi(v) : 24;     // measured best on MI355X at 4096 envs
-        return e < 1 ? 1 : (e > POST_ENVS_MAX ? POST_ENVS_MAX : e);
+        int e = v ? std::atoi(v) : 0;
+        return e < 1 ? 0 : (e > POST_ENVS_MAX ? POST_ENVS_MAX : e);
     }();
+    // envs per manager block, measured on MI355X with the whole-step bench: 16 at 4096 envs (in
+    // the step the manager chain outlasts the cast: 74.6 us/step with 24, 73.3 with 16, 73.5 with 12, 74.9 with 8), a full wave of lanes per term once the cast runs for several rounds (fewer manager blocks
+    // holding wave slots the cast could use; whole-step bench: 204.2 -> 202.0 us at 16384 envs with 32, 743 -> 729 us at
+    // 65536 envs with 64; at 8192 envs 24 is still best)
+    const int post_envs = post_envs_forced > 0 ? post_envs_forced : (num_envs >= 32768 ? 64 : (num_envs >= 12288 ? 32 : (num_envs >= 6144 ? 24 : 16)));
     int threads = threads_env > 0 ? threads_env : 256;
     if (threads_env <= 0 && cast && cast->num_rays > 0 && cast->num_rays < 256)
         threads = (((256 / cast->num_rays) * cast->num_rays + 63) / 64) * 64;   // 187 rays -> 192 threads

@@ -122,6 +122,10 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
             // SensorBase.update of this physics step (sensor_base.py:197-205) + the lazy-evaluation test (:284-293)
             bool od = od_in != 0;
             float t_now = ts_in;
+#ifdef MDP_STAMPS
+            if (pos.x == 1.2345e30f && dr.x == 1.0f && ts_in == last_in) return;   // waits for every input
+            MDP_STAMP(5);
+#endif
             if (a.tick_dt > 0.0f) {
                 t_now += a.tick_dt;
                 a.ts[e] = t_now;
@@ -132,6 +136,10 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
             if (od) {
                 if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
                 Q4 qr = yaw_quat(q);
+#ifdef MDP_STAMPS
+                if (qr.w == 1.2345e30f) return;
+                MDP_STAMP(6);
+#endif
                 se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
                 st3(a.pos_w + 3 * (int64_t)e, pos);
                 st4(a.quat_w + 4 * (int64_t)e, q);

@@ -8,6 +8,8 @@ curriculum) is the reference's host-synchronising path and is optional (SURVEY.m
 """
 from __future__ import annotations
 
+import os
+
 import math
 from typing import Any
 
@@ -152,6 +154,10 @@ class ManagerBasedRLEnv:
         if has_events:
             # event terms write the robot state between rewards and observations: the stages run one after the other
             split = early_cast = concurrent = False
+        if concurrent and not split and not self._has_lazy_sensor() and os.environ.get("MDP_FORCE_CONCURRENT") != "1":
+            # nothing to overlap (a task without ray casters): the second stream would only add its cross-queue
+            # hand-over (~25 us on this stack) to a chain that is serial anyway
+            concurrent = False
         if masked and not (early_cast and self.single_launch_post_physics):
             split = early_cast = concurrent = False   # resets sit between rewards and commands: serial launches below
         self.action_manager.apply_action()
@@ -232,6 +238,9 @@ class ManagerBasedRLEnv:
         self.reset_terminated = self.termination_manager.terminated
         self.reset_time_outs = self.termination_manager.time_outs
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras
+
+    def _has_lazy_sensor(self) -> bool:
+        return any(hasattr(sensor, "fill_scene_tick") for sensor in self.scene.sensors.values())
 
     def _can_fuse_post_physics(self) -> bool:
         tm, rm = self.termination_manager, self.reward_manager

@@ -114,6 +114,9 @@ class InHandManipulationEnv:
         self._obs = f(n, self.num_full_obs)
         self._goal_resets = torch.zeros(n, dtype=torch.bool, device=device)
         self._ccfg = self._make_cfg()
+        # DirectRLEnv.step's host statements around the five methods folded into their launches (mdp_inhand_*_to / _step /
+        # _from_view, include/mdp_hip.h): same buffers, same values; False = one launch per reference statement
+        self.fused_step = True
 
     # -- properties (direct_rl_env.py:228-248) ----------------------------------------------------------
     @property
@@ -150,6 +153,13 @@ class InHandManipulationEnv:
 
     def _apply_action(self) -> None:
         """:97-117: scale -> moving average -> saturate on the actuated joints, targets handed to the articulation."""
+        if self.fused_step:
+            tgt = self.hand.joint_pos_target
+            L.check(L.lib.mdp_inhand_apply_action_to(C.byref(self._ccfg), L.ptr(self.actions), L.ptr(self._act_idx),
+                                                     L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
+                                                     L.ptr(self.cur_targets), L.ptr(self.prev_targets), L.ptr(tgt),
+                                                     tgt.stride(0), L.stream()))
+            return
         L.check(L.lib.mdp_inhand_apply_action(C.byref(self._ccfg), L.ptr(self.actions), L.ptr(self._act_idx),
                                               L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
                                               L.ptr(self.cur_targets), L.ptr(self.prev_targets), L.stream()))
@@ -174,8 +184,34 @@ class InHandManipulationEnv:
                                        L.ptr(time_out), L.stream()))
         return out_of_reach, time_out
 
+    def _dones_step(self) -> None:
+        """direct_rl_env.py:343-346 as one launch: ``episode_length_buf += 1``, ``_get_dones`` written straight into
+        ``reset_terminated`` / ``reset_time_outs``, ``reset_buf = reset_terminated | reset_time_outs``."""
+        L.check(L.lib.mdp_inhand_dones_step(C.byref(self._ccfg), L.ptr(self.object.data.root_state_w),
+                                            L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
+                                            L.ptr(self.successes), L.ptr(self.episode_length_buf),
+                                            L.ptr(self.reset_terminated), L.ptr(self.reset_time_outs),
+                                            L.ptr(self.reset_buf), L.stream()))
+
     def _get_rewards(self) -> torch.Tensor:
         """:140-177 / compute_rewards :377-433"""
+        if self.fused_step:
+            L.check(L.lib.mdp_inhand_rewards_step(C.byref(self._ccfg), L.ptr(self.object.data.root_state_w),
+                                                  L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos),
+                                                  L.ptr(self.goal_rot), L.ptr(self.actions), L.ptr(self.reset_buf),
+                                                  L.ptr(self.reset_goal_buf), L.ptr(self.successes),
+                                                  L.ptr(self.reward_buf), L.ptr(self._partials), L.stream()))
+            if self.group is not None:
+                import torch.distributed as dist
+
+                dist.all_reduce(self._partials, group=self.group)
+            L.check(L.lib.mdp_inhand_finish_rewards_step(C.byref(self._ccfg), L.ptr(self._partials),
+                                                         L.ptr(self.consecutive_successes), L.stream()))
+            if "log" not in self.extras:
+                self.extras["log"] = dict()
+            # the mean of the one-element buffer (:431) is that element: a view, no reduction kernel
+            self.extras["log"]["consecutive_successes"] = self.consecutive_successes[0]
+            return self.reward_buf
         L.check(L.lib.mdp_inhand_rewards(C.byref(self._ccfg), L.ptr(self.object.data.root_state_w),
                                          L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
                                          L.ptr(self.actions), L.ptr(self.reset_buf), L.ptr(self.reset_goal_buf),
@@ -195,6 +231,15 @@ class InHandManipulationEnv:
 
     def compute_full_observations(self) -> torch.Tensor:
         """:298-322"""
+        if self.fused_step:
+            view = self.hand.root_physx_view
+            L.check(L.lib.mdp_inhand_full_obs_from_view(
+                C.byref(self._ccfg), L.ptr(self.hand.data.joint_pos), L.ptr(self.hand.data.joint_vel),
+                L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits), L.ptr(self.object.data.root_state_w),
+                L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
+                L.ptr(view.get_link_transforms()), L.ptr(view.get_link_velocities()), L.ptr(self._fingers),
+                L.ptr(self.actions), self.cfg.action_space, L.ptr(self._obs), self._obs.stride(0), L.stream()))
+            return self._obs
         L.check(L.lib.mdp_inhand_full_obs(C.byref(self._ccfg), L.ptr(self.hand.data.joint_pos),
                                           L.ptr(self.hand.data.joint_vel), L.ptr(self.hand_dof_lower_limits),
                                           L.ptr(self.hand_dof_upper_limits), L.ptr(self.object.data.root_state_w),
@@ -220,6 +265,15 @@ class InHandManipulationEnv:
         self.goal_rot[env_ids] = new_rot
         self.reset_goal_buf[env_ids] = False
 
+    def _update_hand_fused(self, dt: float) -> None:
+        """``self.hand.data.update(dt)`` (articulation_data.py:77-82: timestamp, joint state refresh, joint_acc finite
+        difference) as the one launch InteractiveScene.update uses (``mdp_scene_update``) instead of two copies and a
+        kernel."""
+        d = L.MdpSceneUpdate()
+        self.hand.data.fill_scene_update(d, dt)
+        L.check(L.lib.mdp_scene_update(C.byref(d), float(dt), L.stream()))
+        self.hand.data.commit_scene_update(dt)
+
     # -- stepping (direct_rl_env.py:293-380) ------------------------------------------------------------
     def step(self, action: torch.Tensor, reset_goals: bool = False):
         self._pre_physics_step(action.to(self.device))
@@ -227,14 +281,20 @@ class InHandManipulationEnv:
             self._sim_step_counter += 1
             self._apply_action()
             self.hand_view.advance()                      # sim.step(): synthetic / replayed
-            self.hand.data.update(self.physics_dt)
+            if self.fused_step:
+                self._update_hand_fused(self.physics_dt)
+            else:
+                self.hand.data.update(self.physics_dt)
             self.object.update(self.physics_dt)
-        self.episode_length_buf += 1
         self.common_step_counter += 1
-        terminated, time_outs = self._get_dones()
-        self.reset_terminated[:] = terminated
-        self.reset_time_outs[:] = time_outs
-        torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
+        if self.fused_step:
+            self._dones_step()
+        else:
+            self.episode_length_buf += 1
+            terminated, time_outs = self._get_dones()
+            self.reset_terminated[:] = terminated
+            self.reset_time_outs[:] = time_outs
+            torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
         self.reward_buf = self._get_rewards()
         if reset_goals:                                    # :172-175 (host sync, like the reference)
             goal_env_ids = self.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)

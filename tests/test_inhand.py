@@ -77,12 +77,14 @@ def _feed(env, device, obj, body=None, q=None, qd=None):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fused", (True, False), ids=("fused_step", "one_launch_per_statement"))
 @pytest.mark.parametrize("n", (7, 64))
-def test_gpu_inhand_vs_reference_fixture(golden, device, n):
+def test_gpu_inhand_vs_reference_fixture(golden, device, n, fused):
     G = golden("inhand")
     p = f"n{n}_"
     env = _make_env(n, device, G[p + "origins"], G[p + "lower"], G[p + "upper"], G[p + "act_idx"], G[p + "fingers"],
                     act_moving_average=0.3, max_consecutive_success=3, episode_length_s=10.0)
+    env.fused_step = fused
     assert env.max_episode_length == 600 and env.num_full_obs == 157
     env.in_hand_pos.copy_(to_dev(G[p + "in_hand"], device))
     env.goal_rot.copy_(to_dev(G[p + "goal"], device))
@@ -101,6 +103,13 @@ def test_gpu_inhand_vs_reference_fixture(golden, device, n):
     np.testing.assert_array_equal(to_np(oor), G[p + "out_of_reach"])
     np.testing.assert_array_equal(to_np(to), G[p + "time_out"])
     np.testing.assert_array_equal(to_np(env.episode_length_buf), G[p + "ep_out"])
+    # the same through the step form: episode_length_buf += 1, _get_dones, reset_terminated / _time_outs / reset_buf
+    env.episode_length_buf.copy_(to_dev(G[p + "ep"] - 1, device))
+    env._dones_step()
+    np.testing.assert_array_equal(to_np(env.reset_terminated), G[p + "out_of_reach"])
+    np.testing.assert_array_equal(to_np(env.reset_time_outs), G[p + "time_out"])
+    np.testing.assert_array_equal(to_np(env.reset_buf), G[p + "out_of_reach"] | G[p + "time_out"])
+    np.testing.assert_array_equal(to_np(env.episode_length_buf), G[p + "ep_out"])
     # observations
     assert_close(to_np(env._get_observations()["policy"]), G[p + "full_obs"])
     # _get_rewards
@@ -113,10 +122,15 @@ def test_gpu_inhand_vs_reference_fixture(golden, device, n):
     assert_close(to_np(env.successes), G[p + "successes_out"])
     assert_close(to_np(env.consecutive_successes), G[p + "cons_out"])
     assert float(env.extras["log"]["consecutive_successes"]) == pytest.approx(float(G[p + "cons_out"][0]), rel=1e-5)
+    if fused:      # the partial sums are left zeroed for the next step (mdp_inhand_finish_rewards_step)
+        assert to_np(env._partials).tolist() == [0.0, 0.0]
+        rew2 = env._get_rewards()      # a second evaluation starts from clean sums: same reset count, same average
+        assert np.isfinite(to_np(rew2)).all() and to_np(env._partials).tolist() == [0.0, 0.0]
 
 
 @pytest.mark.gpu
-def test_gpu_inhand_step_full_size_vs_oracle(device):
+@pytest.mark.parametrize("fused", (True, False), ids=("fused_step", "one_launch_per_statement"))
+def test_gpu_inhand_step_full_size_vs_oracle(device, fused):
     """DirectRLEnv.step order at the per-GPU size of BASELINE config C5 (16384 envs, 24 DoF, 5 fingertips)."""
     from oracle import inhand_np as O
 
@@ -127,6 +141,7 @@ def test_gpu_inhand_step_full_size_vs_oracle(device):
     lower = -1.0 - rng.rand(n, D).astype(np.float32)
     upper = 1.0 + rng.rand(n, D).astype(np.float32)
     env = _make_env(n, device, origins, lower, upper, act_moving_average=0.7)
+    env.fused_step = fused
     quat = f(n, 4); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
     goal = f(n, 4); goal /= np.linalg.norm(goal, axis=1, keepdims=True)
     goal[::9] = quat[::9]
@@ -168,3 +183,10 @@ def test_gpu_inhand_step_full_size_vs_oracle(device):
     assert_close(to_np(env.successes), succ)
     assert_close(to_np(env.consecutive_successes), cons)
     assert_close(to_np(obs["policy"]), o)
+    np.testing.assert_array_equal(to_np(env.reset_buf), oor | to)
+    np.testing.assert_array_equal(to_np(env.episode_length_buf), ep)
+    assert_close(to_np(env.hand.joint_pos_target)[:, act_idx], cur[:, act_idx])
+    # joint state buffers of the articulation after the two scene updates (articulation_data.py:77-82, 446-455)
+    assert_close(to_np(env.hand.data.joint_pos), q)
+    assert_close(to_np(env.hand.data.joint_vel), qd)
+    assert np.abs(to_np(env.hand.data.joint_acc)).max() == 0.0      # the frame is held: no velocity change

@@ -66,6 +66,13 @@ def cast_phases(st):
     d = np.diff(seq, axis=1)
     print("           cast phase medians (us): bookkeeping+barriers %.2f  pose+yaw %.2f  ray setup+cell walk %.2f  hit/obs stores %.2f"
           % tuple(np.median(d, axis=0)))
+    if (r[:, 5] != 0).any():   # finer stamps of the bookkeeping lane: 5 = its inputs arrived, 6 = yaw quaternion done
+        b = r[r[:, 5] != 0]
+        fine = np.diff(b[:, [0, 5, 6, 2]] / 100.0, axis=1)
+        print("           bookkeeping lane (us): block start -> inputs arrived %.2f  -> yaw quaternion %.2f  -> stores + barrier passed %.2f"
+              % tuple(np.median(fine, axis=0)))
+        q = b[:, 0] > np.percentile(b[:, 0], 75)
+        print("           same, last-quarter blocks: " + "  ".join("%.2f" % v for v in np.median(fine[q], axis=0)))
     early = r[:, 0] < np.percentile(r[:, 0], 25)
     print("           first-quarter blocks: " + "  ".join("%.2f" % v for v in np.median(d[early], axis=0)),
           "| last-quarter blocks: " + "  ".join("%.2f" % v for v in np.median(d[r[:, 0] > np.percentile(r[:, 0], 75)], axis=0)))
