@@ -1,4 +1,4 @@
-# SQ counters of the cast / post-physics launches for library variants: bash tools/_pmc_variants.sh "main aw1 aw2"
+# SQ counters of the cast / post-physics launches for library variants: bash tools/pmc_variants.sh "main aw1 aw2"
 O=gpurun_out/pmcv; rm -rf $O; mkdir -p $O
 for v in $1; do
   lib=isaaclab_amd/_lib/libmdp_hip_$v.so; [ "$v" = main ] && lib=isaaclab_amd/_lib/libmdp_hip.so
