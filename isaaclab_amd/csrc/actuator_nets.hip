@@ -303,7 +303,7 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
 // row's inputs -- ONE round trip, no LDS staging, no block barrier, no LDS read in front of each MFMA.  The generic
 // kernel above spends 63 % of its wave cycles parked on s_waitcnt (SQ_WAIT_ANY) for exactly those.  Same MFMA / gate
 // order as k_lstm: bit-identical outputs.
-template <int NL>
+template <int NL, bool SLICE>
 __global__ void __launch_bounds__(256)
 k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact, int upd_envs,
             mdp_joint_action_t jact, NetDev net, const float* __restrict__ packed, int64_t rows, int J,
@@ -324,6 +324,14 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
     }
     MDP_STAMP(0, 2);
     const unsigned bid = blockIdx.x - nb_upd;
+    // upd_envs < 0: no update blocks -- every actuator block carries the update of a slice of -upd_envs envs itself: its
+    // requests go out with the rows' own, its results are stored while the gates are evaluated, and the per-env words
+    // are committed behind the block's only barrier at the very end (scene_update_device.hpp: SceneUpdateSlice)
+    SceneUpdateSlice us;
+    const int us_e0 = SLICE && upd_envs < 0 ? (int)bid * -upd_envs : 0;
+    const int us_e1 = SLICE && upd_envs < 0 ? (us_e0 - upd_envs < upd.num_envs ? us_e0 - upd_envs : upd.num_envs) : 0;
+    const bool has_slice = SLICE && us_e0 < us_e1;       // block-uniform
+    if (has_slice) scene_update_slice_request(upd, us_e0, us_e1, us);
     int lane = threadIdx.x & 63;
     int gq = lane >> 4, col = lane & 15;
     int64_t wave = (int64_t)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -377,6 +385,7 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
 #pragma unroll
     for (int r = 0; r < 4; ++r) bm[r] = packed[net.L.mlp_b[0] + r * 64 + lane];
     const int act = net.d.mlp_act[0];
+    if (has_slice) scene_update_slice_store(upd, dt, us);
     while (g < ngroups) {
         const float cx0 = x0, cx1 = x1, clim = lim_r, cvl = vl_r;
         const bool cvalid = valid;
@@ -438,6 +447,10 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
             applied[crr] = tclamp(tau, mn, mx);
         }
         g = gnext;
+    }
+    if (has_slice) {
+        __syncthreads();          // every body thread of the slice has read the words the commit rewrites
+        scene_update_slice_commit(upd, dt, us_e0, us);
     }
     MDP_STAMP(1);
 }
@@ -638,6 +651,19 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     unsigned nb_act = net_grid(rows);
     dim3 grid(nb_act + plan.carried_total), block(256);
     hipStream_t s = as_stream(stream);
+    // register-resident kernel: the update rides inside the actuator blocks when a slice of envs per block fits one
+    // round of their threads (MDP_UPD_INLINE=0: separate update blocks in front of the grid, as for the other kernels)
+    static const bool inline_ok = [] { const char* e = std::getenv("MDP_UPD_INLINE"); return !e || e[0] != '0'; }();
+    // Measured with the whole-step bench: at 16384 envs the launch goes 29.5 -> 25.8 us (step 208.6 -> 203.9 us); at
+    // 8192 envs 15.4 -> 16.7 us and at 4096 envs the slice's registers (64 -> 86 VGPRs) cost more than the update blocks
+    // did (76.8 -> 77.8 us/step when every launch used them), so smaller launches keep the update blocks and the
+    // 64-register instantiation.  Beyond 2048 actuator blocks x 15 envs the slice no longer fits one round.
+    int upd_mode = plan.carried_envs;
+    dim3 grid8 = grid;
+    if (update && inline_ok && num_envs >= 12288) {
+        const int n = scene_update_slice_envs(plan.d, nb_act, 256);
+        if (n > 0) { upd_mode = -n; grid8 = dim3(nb_act); }
+    }
 #define LAUNCH(HH)                                                                                                 \
     do {                                                                                                           \
         if (lds_bytes > 64 * 1024)                                                                                 \
@@ -651,16 +677,26 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     // register-resident weights for the ANYdrive shape (MDP_LSTM_GENERIC=1 forces the LDS kernel: parity tests)
     static const bool force_generic = [] { const char* e = std::getenv("MDP_LSTM_GENERIC"); return e && e[0] == '1'; }();
     if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1 && rows < (1ll << 31)) {
+#define L8(NLAYERS)                                                                                                 \
+    do {                                                                                                            \
+        if (upd_mode < 0)                                                                                           \
+            hipLaunchKernelGGL((k_lstm8_reg<NLAYERS, true>), grid8, block, 0, s, plan.d, dt, nb_act, plan.nb_root,  \
+                               plan.nb_joint, plan.nb_contact, upd_mode, act, net, packed_weights, rows, num_joints, \
+                               q_des, ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state, cell_state,     \
+                               effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort,    \
+                               gate);                                                                               \
+        else                                                                                                        \
+            hipLaunchKernelGGL((k_lstm8_reg<NLAYERS, false>), grid8, block, 0, s, plan.d, dt, nb_act, plan.nb_root, \
+                               plan.nb_joint, plan.nb_contact, upd_mode, act, net, packed_weights, rows, num_joints, \
+                               q_des, ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state, cell_state,     \
+                               effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort,    \
+                               gate);                                                                               \
+    } while (0)
         if (desc->lstm_layers == 1)
-            hipLaunchKernelGGL(k_lstm8_reg<1>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
-                               plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
-                               joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
-                               saturation_effort, computed_effort, applied_effort, gate);
+            L8(1);
         else
-            hipLaunchKernelGGL(k_lstm8_reg<2>, grid, block, 0, s, plan.d, dt, nb_act, plan.nb_root, plan.nb_joint,
-                               plan.nb_contact, plan.carried_envs, act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
-                               joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
-                               saturation_effort, computed_effort, applied_effort, gate);
+            L8(2);
+#undef L8
         MDP_LAUNCH_CHECK();
         return MDP_OK;
     }

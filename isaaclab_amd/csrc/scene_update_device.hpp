@@ -290,6 +290,165 @@ __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, f
     }
 }
 
+// ---- the same update for a SLICE of envs whose items fit one round of the block's threads, in three parts, so that a
+// kernel with work of its own (the actuator-net rows of k_lstm8_reg) can put its own requests between them: everything
+// is requested up front, the results are stored once they are there, and the per-env bookkeeping words -- read by every
+// body thread of the env -- are committed behind a block barrier the caller places at its own end.
+// Requires max(13, J, B) * (e1 - e0) <= blockDim.x (host: scene_update_slice_envs).
+struct SceneUpdateSlice {
+    bool hr, hj, hc, he;
+    float rv; int64_t ro;
+    float qd, qp, pv; int64_t jo;
+    int ce, cb; int64_t ci;
+    float ts, tl, ca, cc; uint8_t flag;
+    V3 f; V3 hrow[3];
+    float ets, etl; uint8_t eflag;                 // env-level copies for the commit
+    float tt[4], ttl[4];
+};
+
+__device__ __forceinline__ void scene_update_slice_request(const mdp_scene_update_t& d, int e0, int e1, SceneUpdateSlice& r) {
+    const int n = e1 - e0;
+    const int J = d.num_joints, B = d.num_contact_bodies, H = d.history_len;
+    const bool has_root = d.root_state_w != nullptr;
+    const bool has_joint = d.joint_vel_src != nullptr && J > 0;
+    const bool has_contact = d.net_contact_forces != nullptr && B > 0;
+    const bool hist_regs = d.net_forces_w_history != nullptr && H > 0 && H <= 4;
+    const int i = threadIdx.x;
+    r.hr = has_root && i < n * 13; r.hj = has_joint && i < n * J; r.hc = has_contact && i < n * B;
+    r.he = i < n;
+    r.rv = 0.0f; r.ro = 0;
+    if (r.hr) {
+        int64_t row = e0 + i / 13;
+        int k = i % 13;
+        r.ro = 13 * row + k;
+        if (k < 3) r.rv = d.root_transforms[7 * row + k];
+        else if (k == 3) r.rv = d.root_transforms[7 * row + 6];
+        else if (k < 7) r.rv = d.root_transforms[7 * row + k - 1];
+        else r.rv = d.root_velocities[6 * row + (k - 7)];
+    }
+    r.qd = 0.0f; r.qp = 0.0f; r.pv = 0.0f; r.jo = 0;
+    if (r.hj) {
+        int64_t e = e0 + i / J;
+        int j = i % J;
+        r.jo = e * J + j;
+        r.qd = d.joint_vel_src[e * d.ld_joint_src + j];
+        if (d.joint_pos) r.qp = d.joint_pos_src[e * d.ld_joint_src + j];
+        if (d.joint_acc) r.pv = d.prev_joint_vel[r.jo];
+    }
+    r.ce = 0; r.cb = 0; r.ci = 0; r.ts = 0.0f; r.tl = 0.0f; r.ca = 0.0f; r.cc = 0.0f; r.flag = 0;
+    r.f = V3{0.0f, 0.0f, 0.0f};
+    if (r.hc) {
+        r.ce = e0 + i / B;
+        r.cb = i % B;
+        r.ci = (int64_t)r.ce * B + r.cb;
+        r.ts = d.contact_timestamp[r.ce];
+        r.tl = d.contact_timestamp_last_update[r.ce];
+        r.flag = d.contact_is_outdated[r.ce];
+        if (d.contact_eager) {
+            r.f = ld3(d.net_contact_forces + 3 * r.ci);
+            if (hist_regs) {
+                const float* hb = d.net_forces_w_history + ((int64_t)r.ce * H * B + r.cb) * 3;
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    if (s < H - 1) r.hrow[s] = ld3(hb + (int64_t)s * B * 3);
+            }
+            if (d.current_air_time) { r.ca = d.current_air_time[r.ci]; r.cc = d.current_contact_time[r.ci]; }
+        }
+    }
+    r.ets = 0.0f; r.etl = 0.0f; r.eflag = 0;
+    const int ee = e0 + i;
+    if (has_contact && r.he) {
+        r.ets = d.contact_timestamp[ee];
+        r.etl = d.contact_timestamp_last_update[ee];
+        r.eflag = d.contact_is_outdated[ee];
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        r.tt[s] = 0.0f; r.ttl[s] = 0.0f;
+        if (s < d.num_ticks && r.he) { r.tt[s] = d.tick_timestamp[s][ee]; r.ttl[s] = d.tick_timestamp_last_update[s][ee]; }
+    }
+}
+
+// results of the round (same expressions as scene_update_envs); no barrier
+__device__ __forceinline__ void scene_update_slice_store(const mdp_scene_update_t& d, float dt, const SceneUpdateSlice& r) {
+    const int B = d.num_contact_bodies, H = d.history_len;
+    const bool hist_regs = d.net_forces_w_history != nullptr && H > 0 && H <= 4;
+    if (r.hr) d.root_state_w[r.ro] = r.rv;
+    if (r.hj) {
+        if (d.joint_vel) d.joint_vel[r.jo] = r.qd;
+        if (d.joint_pos) d.joint_pos[r.jo] = r.qp;
+        if (d.joint_acc) {
+            d.joint_acc[r.jo] = (r.qd - r.pv) / d.acc_elapsed;
+            d.prev_joint_vel[r.jo] = r.qd;
+        }
+    }
+    if (r.hc) {
+        float t_new = r.ts + dt;
+        bool od = (r.flag != 0) || ((t_new - r.tl) + 1e-6f >= d.contact_update_period);
+        if (od && d.contact_eager) {
+            const float elapsed = t_new - r.tl;
+            if (hist_regs || !d.net_forces_w_history || H <= 0) {
+                st3(d.net_forces_w + 3 * r.ci, r.f);
+                if (hist_regs) {
+                    float* hb = d.net_forces_w_history + ((int64_t)r.ce * H * B + r.cb) * 3;
+#pragma unroll
+                    for (int s = 3; s >= 1; --s)
+                        if (s < H) st3(hb + (int64_t)s * B * 3, r.hrow[s - 1]);
+                    st3(hb, r.f);
+                }
+                if (d.current_air_time) {
+                    bool is_contact = norm3(r.f) > d.force_threshold;
+                    bool first_contact = (r.ca > 0.0f) && is_contact;
+                    bool first_detached = (r.cc > 0.0f) && !is_contact;
+                    if (first_contact) d.last_air_time[r.ci] = r.ca + elapsed;
+                    d.current_air_time[r.ci] = !is_contact ? (r.ca + elapsed) : 0.0f;
+                    if (first_detached) d.last_contact_time[r.ci] = r.cc + elapsed;
+                    d.current_contact_time[r.ci] = is_contact ? (r.cc + elapsed) : 0.0f;
+                }
+            } else {
+                contact_body_update(r.ci, r.ce, r.cb, B, H, d.net_contact_forces, d.net_forces_w, d.net_forces_w_history,
+                                    d.last_air_time, d.current_air_time, d.last_contact_time, d.current_contact_time,
+                                    elapsed, d.force_threshold);
+            }
+        }
+    }
+}
+
+// per-env bookkeeping words; the caller has placed a block barrier between the request and this call
+__device__ __forceinline__ void scene_update_slice_commit(const mdp_scene_update_t& d, float dt, int e0, const SceneUpdateSlice& r) {
+    const bool has_contact = d.net_contact_forces != nullptr && d.num_contact_bodies > 0;
+    const int ee = e0 + (int)threadIdx.x;
+    if (!r.he) return;
+    if (has_contact) {
+        float t_new = r.ets + dt;
+        bool od = (r.eflag != 0) || ((t_new - r.etl) + 1e-6f >= d.contact_update_period);
+        d.contact_timestamp[ee] = t_new;
+        if (od && d.contact_eager) {
+            d.contact_timestamp_last_update[ee] = t_new;
+            od = false;
+        }
+        d.contact_is_outdated[ee] = od ? 1 : 0;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        if (s < d.num_ticks) {
+            float t = r.tt[s] + dt;
+            d.tick_timestamp[s][ee] = t;
+            if ((t - r.ttl[s]) + 1e-6f >= d.tick_update_period[s]) d.tick_is_outdated[s][ee] = 1;
+        }
+    }
+}
+
+// envs per block of a slice layout over `blocks` blocks of `threads` threads, or 0 when a slice would not fit one round
+inline int scene_update_slice_envs(const mdp_scene_update_t& d, int64_t blocks, int threads) {
+    if (blocks <= 0 || d.num_envs <= 0) return 0;
+    const int n = (int)((d.num_envs + blocks - 1) / blocks);
+    int widest = 13;
+    if (d.num_joints > widest) widest = d.num_joints;
+    if (d.num_contact_bodies > widest) widest = d.num_contact_bodies;
+    return (int64_t)n * widest <= threads ? n : 0;
+}
+
 struct SceneUpdatePlan {
     mdp_scene_update_t d;
     unsigned nb_root = 0, nb_joint = 0, nb_contact = 0, nb_tick = 0, total = 0;
