@@ -738,6 +738,12 @@ typedef struct {
     float* timestamp_last_update;
     uint8_t* is_outdated;
     const struct mdp_height_scan_obs* scan;
+    /* optional workspace of 8 floats per env owned by this sensor (mdp_post_physics_step only; NULL = none).  With it,
+     * launches of many envs compute the per-env part of the update -- SensorBase.update bookkeeping, sensor pose, yaw
+     * quaternion (ray_caster.py:220-240, sensor_base.py:197-205) -- in a small pass of one thread per env in front of
+     * the post-physics kernel, whose cast blocks then start with their rays instead of waiting on one lane's chain of
+     * cold loads; same values, same buffers written. */
+    float* pose_ws;
 } mdp_raycaster_update_args_t;
 
 int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* update, float physics_dt,

@@ -130,7 +130,7 @@ class MdpRaycasterUpdateArgs(C.Structure):
         ("ray_dirs_local", C.c_void_p), ("max_dist", C.c_float), ("tick_dt", C.c_float),
         ("update_period", C.c_float), ("pad1", C.c_float), ("pos_w", C.c_void_p), ("quat_w", C.c_void_p),
         ("ray_hits_w", C.c_void_p), ("timestamp", C.c_void_p), ("timestamp_last_update", C.c_void_p),
-        ("is_outdated", C.c_void_p), ("scan", C.c_void_p),
+        ("is_outdated", C.c_void_p), ("scan", C.c_void_p), ("pose_ws", C.c_void_p),
     ]
 
 

@@ -914,6 +914,9 @@ struct PostArgs {
 #ifndef MDP_POST_MAX_THREADS
 #define MDP_POST_MAX_THREADS 768
 #endif
+// per-env part of the ray caster's update for every env, in front of k_post_physics when the launch has many envs
+__global__ void __launch_bounds__(256) k_cast_pose(RaycasterUpdateArgs a) { raycaster_pose_pass(a); }
+
 template <int BATCH, bool RESET>
 __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, MDP_POST_MIN_WAVES) k_post_physics(PostArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -1514,6 +1517,18 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         ra.pos_w = cast->pos_w; ra.quat_w = cast->quat_w; ra.hits = cast->ray_hits_w; ra.ts = cast->timestamp;
         ra.ts_last = cast->timestamp_last_update; ra.outdated = cast->is_outdated; ra.tick_dt = cast->tick_dt;
         ra.period = cast->update_period;
+        // Many envs: the cast runs for several rounds of resident blocks and a block's life is what the launch costs, a
+        // third of it one lane's bookkeeping chain (cold loads, atan2f / cosf / sinf) with the ray lanes parked at the
+        // barrier.  From MDP_CAST_POSE_MIN_ENVS envs on that part runs as a pass of its own, one thread per env, in front
+        // of this launch, and the cast blocks pick the result up.  Whole-step bench: 16384 envs 204.0 -> 198.1 us/step
+        // (this launch 112.7 -> 103.2 us), 65536 envs 742.8 -> 703.6 (454 -> 405); at 8192 envs the extra launch cancels
+        // the gain (101.0 -> 101.2) and at 4096 envs it costs 2.3 us, hence the default of 12288.
+        static const int pose_min_envs = [] {
+            const char* v = std::getenv("MDP_CAST_POSE_MIN_ENVS");
+            return v ? std::atoi(v) : 12288;
+        }();
+        ra.pose_ws = cast->pose_ws;
+        ra.pose_ready = (cast->pose_ws != nullptr && pose_min_envs >= 0 && num_envs >= pose_min_envs) ? 1 : 0;
         if (cast->scan && cast->scan->obs) {
             const mdp_height_scan_obs_t* sc = cast->scan;
             MDP_REQUIRE(sc->ld_obs >= sc->col_offset + cast->num_rays && sc->col_offset >= 0, "height-scan columns do not fit");
@@ -1585,6 +1600,12 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
     if (lds > 60 * 1024) return fail(MDP_ERR_UNSUPPORTED, "programs too large for the LDS staging area (%zu B)", lds);
     a.post_envs = post_envs;
     a.nb_post = (unsigned)(((int64_t)num_envs + post_envs - 1) / post_envs);
+    if (cast && a.cast.pose_ready) MDP_REQUIRE(((uintptr_t)a.cast.pose_ws & 15) == 0, "cast: pose_ws must be 16-byte aligned");
+    // every argument check is behind us: the pass in front of the kernel may write the sensor's buffers now
+    auto pose_pass = [&]() {
+        if (cast && a.cast.pose_ready)
+            hipLaunchKernelGGL(k_cast_pose, dim3(grid_for(num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), a.cast);
+    };
     if (reset) {
         MDP_REQUIRE(reset->log && reset->log_sums && (reset->fills || reset->num_fills == 0) && reset->num_fills >= 0,
                     "reset: null pointer");
@@ -1595,8 +1616,10 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         MDP_REQUIRE(post_envs >= 8, "reset: the log_sums workspace is sized for blocks of >= 8 envs (MDP_POST_ENVS=%d)", post_envs);
         a.fills = reset->fills; a.num_fills = reset->num_fills; a.log = reset->log;
         a.log_sums = reset->log_sums; a.max_episode_length_s = reset->max_episode_length_s;
+        pose_pass();
         hipLaunchKernelGGL((k_post_physics<1, true>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
     } else {
+        pose_pass();
         hipLaunchKernelGGL((k_post_physics<1, false>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
     }
     MDP_LAUNCH_CHECK();

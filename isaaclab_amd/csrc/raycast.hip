@@ -879,7 +879,7 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
         ra.pose_xyzw = pose_xyzw; ra.drift = drift; ra.starts_l = ray_starts_local; ra.dirs_l = ray_dirs_local;
         ra.max_dist = max_dist; ra.pos_w = pos_w; ra.quat_w = quat_w; ra.hits = ray_hits_w; ra.ts = timestamp;
         ra.ts_last = timestamp_last_update; ra.outdated = is_outdated; ra.scan = sc; ra.tick_dt = tick_dt;
-        ra.period = update_period; ra.reset_mask = nullptr;
+        ra.period = update_period; ra.reset_mask = nullptr; ra.pose_ws = nullptr; ra.pose_ready = 0;
 #define RCD_LAUNCH(B)                                                                                             \
     hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, block_cap)), dim3(threads), 0,        \
                        as_stream(stream), ra, epb, slot_w)
@@ -919,6 +919,7 @@ extern "C" int mdp_raycaster_update_flagged(int num_envs, const mdp_raycaster_up
     ra.dirs_l = cast->ray_dirs_local; ra.max_dist = cast->max_dist; ra.pos_w = cast->pos_w; ra.quat_w = cast->quat_w;
     ra.hits = cast->ray_hits_w; ra.ts = cast->timestamp; ra.ts_last = cast->timestamp_last_update;
     ra.outdated = cast->is_outdated; ra.period = cast->update_period; ra.reset_mask = reset_mask;
+    ra.pose_ws = nullptr; ra.pose_ready = 0;
     if (cast->scan && cast->scan->obs) {
         const mdp_height_scan_obs_t* sc = cast->scan;
         MDP_REQUIRE(sc->ld_obs >= sc->col_offset + num_rays && sc->col_offset >= 0, "height-scan columns do not fit");

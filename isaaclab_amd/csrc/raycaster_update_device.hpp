@@ -27,6 +27,8 @@ struct RaycasterUpdateArgs {
     mdp_height_scan_obs_t scan;
     float tick_dt, period;
     const uint8_t* reset_mask;   // FLAGGED instantiation only (mdp_raycaster_update_flagged)
+    float* pose_ws;              // (N, 8) {pos.xyz, yaw quaternion (w, z), cast flag, -, -}: filled by raycaster_pose_pass
+    int pose_ready;              // 1: pose_ws holds this step's values (the pass ran in front of this launch)
 };
 
 // height_scan observation column of ray r of env e, written by the cast kernels (mdp_height_scan_obs_t)
@@ -93,6 +95,61 @@ __device__ __forceinline__ void raycaster_down_ray(const RaycasterUpdateArgs& a,
     if (a.scan.obs) scan_store(a.scan, e, r, R, pos.z, hz, seed, epoch, stream);
 }
 
+// Per-env part of the update, one lane per env: SensorBase.update of this physics step (sensor_base.py:197-205), the
+// lazy-evaluation test (:284-293), sensor pose with drift and the yaw-only quaternion (ray_caster.py:220-240); writes
+// the sensor's own buffers and returns {pos.xyz, qr.w, qr.z, cast flag} in se[0..5].
+__device__ __forceinline__ void raycaster_env_bookkeeping(const RaycasterUpdateArgs& a, int e, float* se) {
+    // everything whose address is known up front is requested together (flags, timestamps, pose, drift): one
+    // round trip instead of flags -> pose; envs that turn out not to be outdated only wasted two lines
+    const float* p = a.pose + (int64_t)e * a.ld_pose;
+    const uint8_t od_in = a.outdated ? a.outdated[e] : (uint8_t)1;
+    const float ts_in = a.ts ? a.ts[e] : 0.0f;
+    const float last_in = (a.tick_dt > 0.0f) ? a.ts_last[e] : 0.0f;
+    V3 pos = ld3(p);
+    // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows (w, x, y, z)
+    const Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+    V3 dr{0.0f, 0.0f, 0.0f};
+    if (a.drift) dr = ld3(a.drift + 3 * (int64_t)e);
+    // SensorBase.update of this physics step (sensor_base.py:197-205) + the lazy-evaluation test (:284-293)
+    bool od = od_in != 0;
+    float t_now = ts_in;
+#ifdef MDP_STAMPS
+    if (pos.x == 1.2345e30f && dr.x == 1.0f && ts_in == last_in) return;   // waits for every input
+    MDP_STAMP(5);
+#endif
+    if (a.tick_dt > 0.0f) {
+        t_now += a.tick_dt;
+        a.ts[e] = t_now;
+        if ((t_now - last_in) + 1e-6f >= a.period) od = true;
+    }
+    se[5] = od ? 1.0f : 0.0f;
+    if (od) {
+        if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
+        Q4 qr = yaw_quat(q);
+#ifdef MDP_STAMPS
+        if (qr.w == 1.2345e30f) return;
+        MDP_STAMP(6);
+#endif
+        se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
+        st3(a.pos_w + 3 * (int64_t)e, pos);
+        st4(a.quat_w + 4 * (int64_t)e, q);
+        if (a.ts_last) a.ts_last[e] = t_now;
+        if (a.outdated) a.outdated[e] = 0;
+    }
+}
+
+// The same for every env in a pass of its own (one thread per env) in front of a launch with many envs: the results go
+// to pose_ws (N, 8) and the cast blocks of that launch start with their rays (RaycasterUpdateArgs::pose_ready).
+__device__ __forceinline__ void raycaster_pose_pass(const RaycasterUpdateArgs& a) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= a.N) return;
+    float se[6] = {0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+    raycaster_env_bookkeeping(a, e, se);
+    float4* w = reinterpret_cast<float4*>(a.pose_ws + 8 * (int64_t)e);
+    w[0] = float4{se[0], se[1], se[2], se[3]};
+    w[1] = float4{se[4], se[5], 0.0f, 0.0f};
+}
+
 template <int BATCH>
 __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpdateArgs& a, int epb, int slot_w,
                                                              unsigned block, unsigned nblocks) {
@@ -108,43 +165,14 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
         const int e = base + le;
         const bool active = le < epb && e < N;
         if (active && lr == 0) {
-            // everything whose address is known up front is requested together (flags, timestamps, pose, drift): one
-            // round trip instead of flags -> pose; envs that turn out not to be outdated only wasted two lines
-            const float* p = a.pose + (int64_t)e * a.ld_pose;
-            const uint8_t od_in = a.outdated ? a.outdated[e] : (uint8_t)1;
-            const float ts_in = a.ts ? a.ts[e] : 0.0f;
-            const float last_in = (a.tick_dt > 0.0f) ? a.ts_last[e] : 0.0f;
-            V3 pos = ld3(p);
-            // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows (w, x, y, z)
-            const Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
-            V3 dr{0.0f, 0.0f, 0.0f};
-            if (a.drift) dr = ld3(a.drift + 3 * (int64_t)e);
-            // SensorBase.update of this physics step (sensor_base.py:197-205) + the lazy-evaluation test (:284-293)
-            bool od = od_in != 0;
-            float t_now = ts_in;
-#ifdef MDP_STAMPS
-            if (pos.x == 1.2345e30f && dr.x == 1.0f && ts_in == last_in) return;   // waits for every input
-            MDP_STAMP(5);
-#endif
-            if (a.tick_dt > 0.0f) {
-                t_now += a.tick_dt;
-                a.ts[e] = t_now;
-                if ((t_now - last_in) + 1e-6f >= a.period) od = true;
-            }
             float* se = s_env[le];
-            se[5] = od ? 1.0f : 0.0f;
-            if (od) {
-                if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
-                Q4 qr = yaw_quat(q);
-#ifdef MDP_STAMPS
-                if (qr.w == 1.2345e30f) return;
-                MDP_STAMP(6);
-#endif
-                se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
-                st3(a.pos_w + 3 * (int64_t)e, pos);
-                st4(a.quat_w + 4 * (int64_t)e, q);
-                if (a.ts_last) a.ts_last[e] = t_now;
-                if (a.outdated) a.outdated[e] = 0;
+            if (a.pose_ready) {
+                // the pass in front of this launch did the per-env part: two 16-byte loads of a line that is still on chip
+                const float4* w = reinterpret_cast<const float4*>(a.pose_ws + 8 * (int64_t)e);
+                const float4 w0 = w[0], w1 = w[1];
+                se[0] = w0.x; se[1] = w0.y; se[2] = w0.z; se[3] = w0.w; se[4] = w1.x; se[5] = w1.y;
+            } else {
+                raycaster_env_bookkeeping(a, e, se);
             }
         }
         __syncthreads();

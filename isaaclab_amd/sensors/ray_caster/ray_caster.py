@@ -185,8 +185,16 @@ class RayCaster(SensorBase):
         a.timestamp, a.timestamp_last_update = self._timestamp.data_ptr(), self._timestamp_last_update.data_ptr()
         a.is_outdated = self._is_outdated.data_ptr()
         a.scan = C.cast(C.pointer(scan), C.c_void_p) if scan is not None else None
+        if getattr(self, "_pose_ws", None) is None:
+            import torch
+
+            self._pose_ws = torch.zeros((self._num_envs_ws(), 8), dtype=torch.float32, device=pose.device)
+        a.pose_ws = self._pose_ws.data_ptr()
         self._post_keep = (pose, scan)
         return a
+
+    def _num_envs_ws(self) -> int:
+        return int(self._data.pos_w.shape[0])
 
 
 @configclass
