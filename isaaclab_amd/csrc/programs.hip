@@ -1520,12 +1520,13 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         // Many envs: the cast runs for several rounds of resident blocks and a block's life is what the launch costs, a
         // third of it one lane's bookkeeping chain (cold loads, atan2f / cosf / sinf) with the ray lanes parked at the
         // barrier.  From MDP_CAST_POSE_MIN_ENVS envs on that part runs as a pass of its own, one thread per env, in front
-        // of this launch, and the cast blocks pick the result up.  Whole-step bench: 16384 envs 204.0 -> 198.1 us/step
-        // (this launch 112.7 -> 103.2 us), 65536 envs 742.8 -> 703.6 (454 -> 405); at 8192 envs the extra launch cancels
-        // the gain (101.0 -> 101.2) and at 4096 envs it costs 2.3 us, hence the default of 12288.
+        // of this launch, and the cast blocks -- every ray lane reads its env's row, no LDS hand-over, no barrier -- start
+        // with their rays.  Whole-step bench: 16384 envs 204.0 -> 196.3 us/step (this launch 112.7 -> 98.7 us), 65536
+        // envs 742.8 -> 695.4 (454 -> 389), 8192 envs (H1) 101.0 -> 100.0; at 4096 envs the extra launch costs more than
+        // the blocks gain (73.7 -> 75.8 us/step), hence the default of 8192.
         static const int pose_min_envs = [] {
             const char* v = std::getenv("MDP_CAST_POSE_MIN_ENVS");
-            return v ? std::atoi(v) : 12288;
+            return v ? std::atoi(v) : 8192;
         }();
         ra.pose_ws = cast->pose_ws;
         ra.pose_ready = (cast->pose_ws != nullptr && pose_min_envs >= 0 && num_envs >= pose_min_envs) ? 1 : 0;

@@ -164,20 +164,24 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
     for (int base = block * epb; base < N; base += nblocks * epb) {
         const int e = base + le;
         const bool active = le < epb && e < N;
-        if (active && lr == 0) {
-            float* se = s_env[le];
-            if (a.pose_ready) {
-                // the pass in front of this launch did the per-env part: two 16-byte loads of a line that is still on chip
+        float sv[6] = {0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+        if (a.pose_ready) {
+            // the pass in front of this launch did the per-env part: every ray lane reads the env's 32-byte row itself
+            // (one request per wave, the line is still on chip) -- no LDS hand-over, no barrier, the waves run free
+            if (active) {
                 const float4* w = reinterpret_cast<const float4*>(a.pose_ws + 8 * (int64_t)e);
                 const float4 w0 = w[0], w1 = w[1];
-                se[0] = w0.x; se[1] = w0.y; se[2] = w0.z; se[3] = w0.w; se[4] = w1.x; se[5] = w1.y;
-            } else {
-                raycaster_env_bookkeeping(a, e, se);
+                sv[0] = w0.x; sv[1] = w0.y; sv[2] = w0.z; sv[3] = w0.w; sv[4] = w1.x; sv[5] = w1.y;
             }
+        } else {
+            if (active && lr == 0) raycaster_env_bookkeeping(a, e, s_env[le]);
+            __syncthreads();
+            const float* sl = s_env[active ? le : 0];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sv[k] = sl[k];
         }
-        __syncthreads();
         MDP_STAMP(2);
-        const float* se = s_env[active ? le : 0];
+        const float* se = sv;
         const bool od = active && se[5] != 0.0f;
         if (active && !od && scan.obs) {
             float sz = a.pos_w[3 * (int64_t)e + 2];
@@ -189,7 +193,7 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
             MDP_STAMP(3);
             for (int r = lr; r < R; r += slot_w) raycaster_down_ray<BATCH>(a, e, r, pos, qr, seed, epoch);
         }
-        __syncthreads();   // s_env is rewritten by the next env group
+        if (!a.pose_ready) __syncthreads();   // s_env is rewritten by the next env group
     }
     if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
 }
