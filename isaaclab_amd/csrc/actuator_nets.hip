@@ -601,7 +601,8 @@ extern "C" int mdp_net_pack(const mdp_net_desc_t* desc, const float* const* weig
 static unsigned net_grid(int64_t rows) {
     int64_t groups = (rows + 15) / 16;
     int64_t blocks = (groups + 3) / 4;  // 4 waves per block
-    if (blocks > 2048) blocks = 2048;
+    static const int64_t cap = [] { const char* e = std::getenv("MDP_NET_GRID_CAP"); return e ? (int64_t)std::atoll(e) : (int64_t)2048; }();
+    if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     return (unsigned)blocks;
 }
