@@ -911,6 +911,11 @@ struct PostArgs {
 #ifndef MDP_POST_MIN_WAVES
 #define MDP_POST_MIN_WAVES 6
 #endif
+// the instantiation with the reset branch keeps more live state: at 6 waves it spilled 160 B per lane; 5 waves (96
+// registers, 16 B of scratch) is the faster budget for it (--auto-reset masked: 117.6 -> 114.1 us/step, 4 waves 117.7)
+#ifndef MDP_POST_MIN_WAVES_RESET
+#define MDP_POST_MIN_WAVES_RESET 5
+#endif
 #ifndef MDP_POST_MAX_THREADS
 #define MDP_POST_MAX_THREADS 768
 #endif
@@ -918,7 +923,7 @@ struct PostArgs {
 __global__ void __launch_bounds__(256) k_cast_pose(RaycasterUpdateArgs a) { raycaster_pose_pass(a); }
 
 template <int BATCH, bool RESET>
-__global__ void __launch_bounds__(MDP_POST_MAX_THREADS, MDP_POST_MIN_WAVES) k_post_physics(PostArgs a) {
+__global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAVES_RESET : MDP_POST_MIN_WAVES) k_post_physics(PostArgs a) {
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
         MDP_STAMP(0, 1);
