@@ -118,6 +118,17 @@ class InHandManipulationEnv:
         # _from_view, include/mdp_hip.h): same buffers, same values; False = one launch per reference statement
         self.fused_step = True
 
+    @property
+    def fused_step(self) -> bool:
+        return self._fused_step
+
+    @fused_step.setter
+    def fused_step(self, value: bool) -> None:
+        # the step form expects clean partial sums on entry (it leaves them clean itself); the per-method form leaves
+        # the last step's sums behind -- switching forms starts from zero
+        self._fused_step = bool(value)
+        self._partials.zero_()
+
     # -- properties (direct_rl_env.py:228-248) ----------------------------------------------------------
     @property
     def physics_dt(self) -> float: return self.cfg.sim_dt
