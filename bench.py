@@ -118,7 +118,7 @@ def algorithmic_bytes(env) -> dict:
         # launch structure of the default step: the actuator launches of sub-steps 2..D carry the scene update of the
         # sub-step before them, and everything after the last physics step is ONE launch (mdp_post_physics_step)
         act, upd = table["actuator"][0], table["scene_update"][0]
-        post = upd + sum(table[k][0] for k in ("term_reward", "command", "observation", "raycast"))
+        post = upd + sum(table[k][0] for k in ("term_reward", "command", "observation", "raycast") if k in table)
         folded = env.fold_action and env.action_manager._fused_term is not None \
             and env.action_manager._fused_term.can_fold_into_actuator()
         table = {
@@ -554,9 +554,10 @@ def measure_roofline(env, args) -> dict:
     sensors = env.scene.sensors
     split = env.observation_manager.can_split_sensor_terms()
     if "post_physics" in table:
-        hs = sensors["height_scanner"]
-        period = hs.cfg.update_period
-        hs.cfg.update_period = 0.0          # every timed launch must cast (the step casts once per env-step)
+        hs = sensors.get("height_scanner")
+        if hs is not None:
+            period = hs.cfg.update_period
+            hs.cfg.update_period = 0.0      # every timed launch must cast (the step casts once per env-step)
         raw_action = env.action_manager.action.clone()
 
         def action_actuator():
@@ -577,7 +578,8 @@ def measure_roofline(env, args) -> dict:
             nbytes, launches, frag = table[name]
             per_kernel[name] = {"kernel": frag, "us": 1e6 * dur, "launches_per_step": launches,
                                 "alg_bytes_per_env": nbytes, "GBps": nbytes * N / dur / 1e9}
-        hs.cfg.update_period = period
+        if hs is not None:
+            hs.cfg.update_period = period
         roof = _roofline_summary(table, per_kernel, N)
         mfma = _mfma_summary(env, per_kernel)
         if mfma is not None:

@@ -149,11 +149,16 @@ class ManagerBasedRLEnv:
         # sensor-owned observation columns (height scan) come from the cast kernel, on its own stream
         split = concurrent and om.can_split_sensor_terms()
         early_cast = split and self.scene.fused_update and len(om.scan_sensors()) > 0
+        # a task without ray casters: the same single launch, manager blocks only (the flat velocity tasks)
+        flat_single = (concurrent and split and not early_cast and self.scene.fused_update and self.single_launch_post_physics
+                       and not self._has_lazy_sensor() and os.environ.get("MDP_FLAT_SINGLE_LAUNCH") != "0")
         has_events = (any(m in self.event_manager.available_modes for m in ("reset", "interval"))
                       or len(self.curriculum_manager.active_terms) > 0)
         if has_events:
             # event terms write the robot state between rewards and observations: the stages run one after the other
-            split = early_cast = concurrent = False
+            split = early_cast = concurrent = flat_single = False
+        if masked:
+            flat_single = False
         if concurrent and not split and not self._has_lazy_sensor() and os.environ.get("MDP_FORCE_CONCURRENT") != "1":
             # nothing to overlap (a task without ray casters): the second stream would only add its cross-queue
             # hand-over (~25 us on this stack) to a chain that is serial anyway
@@ -174,12 +179,19 @@ class ManagerBasedRLEnv:
                 else:
                     self.scene.update(dt=self.physics_dt)
                     self.scene.write_data_to_sim()
-            elif not early_cast:
+            elif not early_cast and not flat_single:
                 self.scene.update(dt=self.physics_dt)
             # (with early_cast the last scene.update runs after the loop, next to or inside the post-physics launches)
         self.common_step_counter += 1
         if early_cast and self.single_launch_post_physics and self._post_physics_single_launch(reset=masked):
             pass
+        elif flat_single and self._post_physics_single_launch():
+            pass
+        elif flat_single:                               # the launch declined the task: the last update is still due
+            self.scene.update(dt=self.physics_dt)
+            self._termination_reward_fused()
+            self.command_manager.compute(dt=self.step_dt)
+            self.obs_buf = self.observation_manager.compute()
         elif concurrent and not masked:
             # Without the reset path between them (manager_based_rl_env.py:214-229) the chain terminations -> rewards ->
             # command update -> observations and the height-scan cast do not depend on each other: they go to two
@@ -273,9 +285,12 @@ class ManagerBasedRLEnv:
         terms = list(cm._terms.values())
         if len(terms) != 1 or not hasattr(terms[0], "fill_post_physics"):
             return False
-        if not (sensor._pattern_vertical_down and sensor.cfg.attach_yaw_only and self._mesh_has_grid(sensor._mesh)):
+        if sensor is not None and not (sensor._pattern_vertical_down and sensor.cfg.attach_yaw_only
+                                       and self._mesh_has_grid(sensor._mesh)):
             return False
-        plan = self.scene._scene_update_desc(self.physics_dt, skip_ticks=(sensor,))
+        if sensor is None and reset:
+            return False
+        plan = self.scene._scene_update_desc(self.physics_dt, skip_ticks=(sensor,) if sensor is not None else ())
         if plan is None:
             return False
         d, art = plan
@@ -293,11 +308,12 @@ class ManagerBasedRLEnv:
         if self.obs_normalizer is not None and self._normalize_group == group_name:
             na = self._normalize_args(out.shape[1])
             obs_args.normalize = na
-            scan.normalize = na
+            if scan is not None:
+                scan.normalize = na
             self._normalized_in_kernel = True
-        else:
+        elif scan is not None:
             scan.normalize.out = None
-        cast = sensor.fill_post_physics(scan, self.physics_dt)
+        cast = sensor.fill_post_physics(scan, self.physics_dt) if sensor is not None else None
         oprog.run_before()
         if reset:
             # reset branch inside the launch; the ray caster's own reset follows it (see mdp_post_physics_step_with_reset)
@@ -327,7 +343,8 @@ class ManagerBasedRLEnv:
             self._publish_reset_log()
         else:
             L.check(L.lib.mdp_post_physics_step(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
-                                                C.byref(obs_args), C.byref(cast), L.stream(self.device)))
+                                                C.byref(obs_args), C.byref(cast) if cast is not None else None,
+                                                L.stream(self.device)))
         self.reset_buf = tm._dones_buf
         self.reward_buf = rm._reward_buf
         om._obs_buffer = {group_name: out}

@@ -254,11 +254,12 @@ class ObservationManager(ManagerBase):
             return None
         group_name = next(iter(self._group_obs_term_names))
         scans = self._scans.get(group_name, [])
-        if len(scans) != 1 or self._external[group_name]:
+        if len(scans) > 1 or self._external[group_name]:
             return None
         prog, out = self._programs[group_name], self._out_buffers[group_name]
-        sensor, scan = scans[0]
-        scan.obs, scan.ld_obs = out.data_ptr(), out.shape[1]
+        sensor, scan = scans[0] if scans else (None, None)      # a task without a height scan: no cast blocks
+        if scan is not None:
+            scan.obs, scan.ld_obs = out.data_ptr(), out.shape[1]
         a = L.MdpObsArgs()
         a.program, a.obs, a.ld_obs = prog.handle, out.data_ptr(), out.shape[1]
         return a, sensor, scan, prog, group_name, out

@@ -47,13 +47,16 @@ def compare(outs, ref):
         assert_close(got[0], exp[0], rtol=1e-5, atol=1e-5, msg=f"obs step {t}")
 
 
-@pytest.mark.parametrize("n", (7, 256))
-def test_anymal_d_flat(device, n):
-    """BASELINE config C1 (flat, DC motor, 48-dim observation)."""
+@pytest.mark.parametrize("n,persistent", ((7, False), (256, False), (64, True), (203, True)))
+def test_anymal_d_flat(device, n, persistent):
+    """BASELINE config C1 (flat, DC motor, 48-dim observation).  With persistent observation buffers everything after
+    the last physics sub-step is ONE launch here too (mdp_post_physics_step without a cast: manager blocks only; 203
+    envs: ragged last block)."""
     from oracle.harness import replay_oracle
 
-    env, rec, outs = run_env("anymal_d_flat", n, 6, device, seed=11)
+    env, rec, outs = run_env("anymal_d_flat", n, 6, device, seed=11, persistent=persistent)
     assert outs[0][0].shape == (n, 48)
+    assert getattr(env, "_single_launch_steps", 0) == (5 if persistent else 0)
     compare(outs, replay_oracle(rec, 6))
 
 

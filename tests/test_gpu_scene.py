@@ -252,8 +252,8 @@ def test_stats_kernels(device):
     vals = rng.randn(5, 1000).astype(np.float32)
     mask = rng.rand(1000) < 0.3
     out = torch.zeros(10, dtype=torch.float64, device=device)
-    L.check(L.lib.mdp_stats_masked_sums(L.ptr(to_dev(vals, device)), 5, 1000, L.ptr(to_dev(mask, device)), L.ptr(out),
-                                        L.stream()))
+    d_vals, d_mask = to_dev(vals, device), to_dev(mask, device)     # named: the launch borrows the pointers
+    L.check(L.lib.mdp_stats_masked_sums(L.ptr(d_vals), 5, 1000, L.ptr(d_mask), L.ptr(out), L.stream()))
     o = to_np(out).reshape(5, 2)
     np.testing.assert_allclose(o[:, 0], vals.astype(np.float64)[:, mask].sum(1), rtol=1e-12, atol=1e-9)
     assert np.all(o[:, 1] == mask.sum())
