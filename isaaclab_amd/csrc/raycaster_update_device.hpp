@@ -202,8 +202,12 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
 // count as outdated, there is no tick, and only outdated envs are cast (the others keep their observation columns).
 // Few envs are flagged in a step, so a block looks at RCF_ENVS envs with one lane each -- bookkeeping, pose, yaw
 // quaternion -- and then casts the flagged ones one after the other with all its threads: a launch with nothing to do
-// is N / RCF_ENVS blocks that read three flags per env and leave.
-constexpr int RCF_ENVS = 16;
+// is N / RCF_ENVS blocks that read three flags per env and leave (4 envs per block: --auto-reset masked 113.9 -> 112.6 us/step
+// against 16; a block with two flagged envs casts them one after the other).
+#ifndef MDP_RCF_ENVS
+#define MDP_RCF_ENVS 4
+#endif
+constexpr int RCF_ENVS = MDP_RCF_ENVS;
 
 template <int BATCH>
 __device__ __forceinline__ void raycaster_update_flagged_blocks(const RaycasterUpdateArgs& a, unsigned block) {
