@@ -661,7 +661,8 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     // 64-register instantiation.  Beyond 2048 actuator blocks x 15 envs the slice no longer fits one round.
     int upd_mode = plan.carried_envs;
     dim3 grid8 = grid;
-    if (update && inline_ok && num_envs >= 12288) {
+    static const int inline_min_envs = [] { const char* e = std::getenv("MDP_UPD_INLINE_MIN_ENVS"); return e ? std::atoi(e) : 12288; }();
+    if (update && inline_ok && num_envs >= inline_min_envs) {
         const int n = scene_update_slice_envs(plan.d, nb_act, 256);
         if (n > 0) { upd_mode = -n; grid8 = dim3(nb_act); }
     }
