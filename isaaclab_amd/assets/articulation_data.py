@@ -113,8 +113,8 @@ class ArticulationData:
     @property
     def root_link_state_w(self):
         if self._root_link_state_w.timestamp < self._sim_timestamp:
-            L.check(L.lib.mdp_link_state_from_com(self._num_instances, L.ptr(self.root_state_w),
-                                                  L.ptr(self.com_pos_b[:, 0, :].contiguous()),
+            com = self.com_pos_b[:, 0, :].contiguous()     # named: stays allocated until the launch is queued
+            L.check(L.lib.mdp_link_state_from_com(self._num_instances, L.ptr(self.root_state_w), L.ptr(com),
                                                   L.ptr(self._root_link_state_w.data), L.stream()))
             self._root_link_state_w.timestamp = self._sim_timestamp
         return self._root_link_state_w.data
@@ -130,9 +130,9 @@ class ArticulationData:
     @property
     def body_link_state_w(self):
         if self._body_link_state_w.timestamp < self._sim_timestamp:
+            com = self.com_pos_b.contiguous()
             L.check(L.lib.mdp_link_state_from_com(self._num_instances * self._num_bodies, L.ptr(self.body_state_w),
-                                                  L.ptr(self.com_pos_b.contiguous()),
-                                                  L.ptr(self._body_link_state_w.data), L.stream()))
+                                                  L.ptr(com), L.ptr(self._body_link_state_w.data), L.stream()))
             self._body_link_state_w.timestamp = self._sim_timestamp
         return self._body_link_state_w.data
 
