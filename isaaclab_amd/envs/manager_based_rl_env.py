@@ -39,6 +39,10 @@ class ManagerBasedRLEnv:
         # last scene.update + terminations + rewards + command + observations + height-scan cast in one launch
         self.single_launch_post_physics = True
         self.post_reset_noalloc = False  # masked resets inside that launch: use the allocation-free entry point
+        # extras["log"] of a masked reset: 0 = a fresh copy every step (the reference's dict of new tensors); R > 0 = the
+        # launches publish into a ring of R buffers and extras["log"] holds views of them, valid for R - 1 further steps
+        # (no copy launch in the step: a training loop that reads its logs within R steps, e.g. once per rollout)
+        self.reset_log_ring = 0
         # (terminations + rewards, command) and the height-scan cast on two streams (only without a reset in between)
         self.concurrent_post_physics = torch.device(device).type == "cuda"
         if self.concurrent_post_physics:
@@ -324,6 +328,7 @@ class ManagerBasedRLEnv:
                 self._post_reset_sums = torch.zeros(1 + rows * ((self.num_envs + 7) // 8), dtype=torch.float64,
                                                     device=self.device)
                 self._post_reset_log = torch.zeros(rows, dtype=torch.float32, device=self.device)
+            self._next_reset_log()
             _, count, _, blob = self._post_reset_plan
             ra = L.MdpPostResetArgs()
             ra.fills, ra.num_fills, ra.max_episode_length_s = blob.data_ptr(), count, float(self.max_episode_length_s)
@@ -352,11 +357,24 @@ class ManagerBasedRLEnv:
         self._single_launch_steps = getattr(self, "_single_launch_steps", 0) + 1
         return True
 
+    def _next_reset_log(self):
+        """With ``reset_log_ring`` = R > 0: point ``_post_reset_log`` at the next of R buffers (this step's log)."""
+        R = int(self.reset_log_ring)
+        if R <= 0:
+            return
+        ring = getattr(self, "_post_reset_log_ring", None)
+        if ring is None or ring.shape[0] != R:
+            ring = torch.zeros((R, self._post_reset_log.shape[0]), dtype=torch.float32, device=self.device)
+            self._post_reset_log_ring, self._post_reset_log_slot = ring, 0
+        self._post_reset_log = ring[self._post_reset_log_slot]
+        self._post_reset_log_slot = (self._post_reset_log_slot + 1) % R
+
     def _publish_reset_log(self):
         """``extras["log"]`` of the step: views of a copy of the values the post-physics launch published (device
         tensors; reward_manager.py:115-121, command_manager.py:131-136, termination_manager.py:149-150)."""
         rm, tm, cm = self.reward_manager, self.termination_manager, self.command_manager
-        p = self._post_reset_log.clone()        # the launch overwrites its buffer next step; callers keep these
+        # the launch overwrites its buffer next step and callers keep these: a copy, or this step's slot of the ring
+        p = self._post_reset_log if int(self.reset_log_ring) > 0 else self._post_reset_log.clone()
         nr = len(rm.active_terms)
         log = {}
         for i, name in enumerate(rm.active_terms):
@@ -509,6 +527,7 @@ class ManagerBasedRLEnv:
             if getattr(self, "_post_reset_log", None) is None:
                 rows = 1 + len(rm.active_terms) + 2 + len(tm.active_terms)
                 self._post_reset_log = torch.zeros(rows, dtype=torch.float32, device=self.device)
+            self._next_reset_log()
             L.check(L.lib.mdp_reset_log(
                 self.num_envs, mask.data_ptr(), rm._episode_sums_block.data_ptr(), len(rm.active_terms),
                 terms[0].metrics["error_vel_xy"].data_ptr(), terms[0].metrics["error_vel_yaw"].data_ptr(),

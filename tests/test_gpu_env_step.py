@@ -480,3 +480,35 @@ def test_normalised_observation_written_by_the_producing_kernels(device, mode):
         assert_close(to_np(storage[t, :, :235]), orc.compute(to_np(raw)), rtol=1e-5, atol=1e-6, msg=f"step {t}")
     assert getattr(env, "_single_launch_steps", 0) == steps - 1
     assert (storage[..., 235:] == 7.0).all() and float(storage[..., :235].abs().max()) <= 5.0
+
+
+@pytest.mark.parametrize("single_launch", (True, False))
+def test_reset_log_ring(device, single_launch):
+    """``env.reset_log_ring = R``: the masked reset publishes extras["log"] as views of a ring of R buffers instead of a
+    fresh copy per step -- same values as the default, and a step's log stays intact for R - 1 further steps."""
+    import torch
+
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+
+    n, steps, R = 96, 8, 4
+    runs = []
+    for ring in (0, R):
+        env, rec = make_velocity_env("anymal_c_rough", num_envs=n, device=str(device), steps=steps, seed=31,
+                                     small_terrain=True, mesh_accel="grid")
+        env.auto_reset = "masked"
+        env.reset_log_ring = ring
+        env.observation_manager.persistent_output = single_launch
+        g = torch.Generator().manual_seed(5)
+        env.episode_length_buf.copy_(env.max_episode_length - torch.randint(1, steps + 3, (n,), generator=g))
+        held, at_step = [], []
+        for t in range(steps):
+            rec.feed(t)
+            env.step(rec.actions[t].to(device))
+            held.append(env.extras["log"])                                  # kept as the caller would keep it
+            at_step.append({k: float(v) for k, v in env.extras["log"].items()})
+            if ring and t >= R - 1:                                         # R - 1 steps later the views still hold
+                old = {k: float(v) for k, v in held[t - (R - 1)].items()}
+                assert old == at_step[t - (R - 1)]
+        runs.append(at_step)
+    assert runs[0] == runs[1]
+    assert any(v != 0.0 for step in runs[0] for v in step.values())
