@@ -43,6 +43,7 @@ class ManagerBasedRLEnv:
         # launches publish into a ring of R buffers and extras["log"] holds views of them, valid for R - 1 further steps
         # (no copy launch in the step: a training loop that reads its logs within R steps, e.g. once per rollout)
         self.reset_log_ring = 0
+        self.concurrent_reset_tail = os.environ.get("MDP_CONCURRENT_RESET_TAIL", "1") != "0"
         # (terminations + rewards, command) and the height-scan cast on two streams (only without a reset in between)
         self.concurrent_post_physics = torch.device(device).type == "cuda"
         if self.concurrent_post_physics:
@@ -341,10 +342,25 @@ class ManagerBasedRLEnv:
                 launch = L.lib.mdp_post_physics_step_with_reset_noalloc
             L.check(launch(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca), C.byref(obs_args),
                            C.byref(cast), C.byref(ra), L.stream(self.device)))
-            # RayCaster.reset of the done envs + their recast (the observation's lazy evaluation in the reference)
-            L.check(L.lib.mdp_raycaster_update_flagged(self.num_envs, C.byref(cast), tm._dones_buf.data_ptr(),
-                                                       L.stream(self.device)))
-            self.scene.write_data_to_sim(gate=self._post_reset_log)    # log[0] = number of reset envs
+            # RayCaster.reset of the done envs + their recast (the observation's lazy evaluation in the reference) and the
+            # reference's post-reset write_data_to_sim (gate: log[0] = number of reset envs).  Neither reads what the
+            # other writes (sensor buffers + scan columns / actuator state + joint efforts), and both are short chains of
+            # dependent loads: on two streams (two branches of a captured hipGraph) they cost the longer one.
+            if self.concurrent_reset_tail and self.concurrent_post_physics:
+                main = torch.cuda.current_stream(self.device)
+                side = self._side_stream
+                self._ev_scene.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(self._ev_scene)
+                    L.check(L.lib.mdp_raycaster_update_flagged(self.num_envs, C.byref(cast), tm._dones_buf.data_ptr(),
+                                                               L.stream(self.device)))
+                    self._ev_side.record(side)
+                self.scene.write_data_to_sim(gate=self._post_reset_log)
+                main.wait_event(self._ev_side)
+            else:
+                L.check(L.lib.mdp_raycaster_update_flagged(self.num_envs, C.byref(cast), tm._dones_buf.data_ptr(),
+                                                           L.stream(self.device)))
+                self.scene.write_data_to_sim(gate=self._post_reset_log)
             self._publish_reset_log()
         else:
             L.check(L.lib.mdp_post_physics_step(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
