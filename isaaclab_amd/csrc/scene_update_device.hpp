@@ -142,6 +142,23 @@ __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, f
     const int n_root = has_root ? n * 13 : 0, n_joint = has_joint ? n * J : 0, n_contact = has_contact ? n * B : 0;
     int rounds_items = n_root > n_joint ? n_root : n_joint;
     if (n_contact > rounds_items) rounds_items = n_contact;
+    // bookkeeping words: requested up front, together with the first round's inputs (one round trip, not two), committed
+    // behind the barrier at the end (every body thread has read them by then; nobody else writes them)
+    float bts = 0.0f, btl = 0.0f;
+    uint8_t bflag = 0;
+    const int ee = e0 + (int)threadIdx.x;
+    const bool he = (int)threadIdx.x < n;
+    if (has_contact && he) {
+        bts = d.contact_timestamp[ee];
+        btl = d.contact_timestamp_last_update[ee];
+        bflag = d.contact_is_outdated[ee];
+    }
+    float tt[TICKS], ttl[TICKS];
+#pragma unroll
+    for (int s = 0; s < TICKS; ++s) {
+        tt[s] = 0.0f; ttl[s] = 0.0f;
+        if (s < d.num_ticks && he) { tt[s] = d.tick_timestamp[s][ee]; ttl[s] = d.tick_timestamp_last_update[s][ee]; }
+    }
     for (int base = 0; base < rounds_items; base += blockDim.x) {
         const int i = base + threadIdx.x;
         const bool hr = i < n_root, hj = i < n_joint, hc = i < n_contact;
@@ -233,26 +250,10 @@ __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, f
             }
         }
     }
-    // bookkeeping words: requested before the barrier, committed after it (every body thread has read them by then)
-    float ts = 0.0f, tl = 0.0f;
-    uint8_t flag = 0;
-    const int ee = e0 + (int)threadIdx.x;
-    const bool he = (int)threadIdx.x < n;
-    if (has_contact && he) {
-        ts = d.contact_timestamp[ee];
-        tl = d.contact_timestamp_last_update[ee];
-        flag = d.contact_is_outdated[ee];
-    }
-    float tt[TICKS], ttl[TICKS];
-#pragma unroll
-    for (int s = 0; s < TICKS; ++s) {
-        tt[s] = 0.0f; ttl[s] = 0.0f;
-        if (s < d.num_ticks && he) { tt[s] = d.tick_timestamp[s][ee]; ttl[s] = d.tick_timestamp_last_update[s][ee]; }
-    }
     __syncthreads();
     if (has_contact && he) {
-        float t_new = ts + dt;
-        bool od = (flag != 0) || ((t_new - tl) + 1e-6f >= d.contact_update_period);
+        float t_new = bts + dt;
+        bool od = (bflag != 0) || ((t_new - btl) + 1e-6f >= d.contact_update_period);
         d.contact_timestamp[ee] = t_new;
         if (od && d.contact_eager) {
             d.contact_timestamp_last_update[ee] = t_new;
