@@ -331,7 +331,8 @@ def main():
                        "region_ms_p10": 1e3 * float(np.percentile(times, 10)),
                        "region_ms_p90": 1e3 * float(np.percentile(times, 90)), "first_region_ms": 1e3 * first,
                        "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset, "events": bool(args.events), "normalize_obs": bool(args.normalize_obs),
-                       "reset_envs_last_step": resets},
+                       "reset_envs_last_step": resets,
+                       "reset_log_ring": int(getattr(env, "reset_log_ring", 0) or 0)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
