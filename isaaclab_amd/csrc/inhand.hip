@@ -86,7 +86,15 @@ __global__ void k_rewards(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, c
         float rot_rew = 1.0f / (fabsf(rot_dist) + cfg.rot_eps) * cfg.rot_reward_scale;
         float ap = 0.0f;
         int A = cfg.num_actuated;
-        for (int k = 0; k < A; ++k) { float a = actions[(int64_t)e * A + k]; ap += a * a; }
+        const float* arow = actions + (int64_t)e * A;
+        if ((A & 3) == 0 && ((uintptr_t)actions & 15) == 0) {      // same sum order, four columns per load
+            for (int k = 0; k < A; k += 4) {
+                const float4 a4 = *reinterpret_cast<const float4*>(arow + k);
+                ap += a4.x * a4.x; ap += a4.y * a4.y; ap += a4.z * a4.z; ap += a4.w * a4.w;
+            }
+        } else {
+            for (int k = 0; k < A; ++k) { float a = arow[k]; ap += a * a; }
+        }
         float rew = (dist_rew + rot_rew) + ap * cfg.action_penalty_scale;
         uint8_t gr = (fabsf(rot_dist) <= cfg.success_tolerance) ? 1 : reset_goal_buf[e];
         float succ = successes[e] + (float)gr;
@@ -100,14 +108,23 @@ __global__ void k_rewards(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, c
         my_resets = (double)resets;
         my_succ = (double)(succ * (float)resets);
     }
-    // wave reduction then one fp64 atomic pair per wave
+    // wave reduction, the block's waves through LDS, then one fp64 atomic pair per block (both sums are sums of
+    // integer-valued terms: exact in any order); all of them land on the same two words, so fewer is faster
+    __shared__ double s_part[2][16];
     for (int off = 32; off > 0; off >>= 1) {
         my_resets += __shfl_down(my_resets, off);
         my_succ += __shfl_down(my_succ, off);
     }
-    if ((threadIdx.x & 63) == 0 && (my_resets != 0.0 || my_succ != 0.0)) {
-        atomicAdd(&partials[0], my_resets);
-        atomicAdd(&partials[1], my_succ);
+    const int wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { s_part[0][wave] = my_resets; s_part[1][wave] = my_succ; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0, q = 0.0;
+        for (int w = 0; w < nw; ++w) { r += s_part[0][w]; q += s_part[1][w]; }
+        if (r != 0.0 || q != 0.0) {
+            atomicAdd(&partials[0], r);
+            atomicAdd(&partials[1], q);
+        }
     }
 }
 
@@ -122,7 +139,21 @@ __global__ void k_finish_rewards(mdp_inhand_cfg_t cfg, const double* __restrict_
     }
 }
 
-// :298-322, one thread per (env, column); block owns whole envs
+// :298-322.  A block owns FULL_OBS_EPB whole envs.  Which array, row stride, offset and operation a column takes does not
+// depend on the env, so the block lowers the column list ONCE into descriptors in LDS (one pass of the branch chain per
+// column) and then every (env, column) element costs a descriptor read, up to three loads issued together, a select
+// and a store -- with a flat 64-bit index per element the division and the branch chain were ~200 vector instructions
+// per element and the kernel was issue-bound (23 us for 20 MB).  v = scale * a | a - b | unscale(a, b, c) | one
+// component of the quaternion difference; 1.0f * a == a bit for bit, so plain copies share the scaled form.
+constexpr int FULL_OBS_EPB = 8;
+struct FullObsCol {
+    const float* pa; const float* pb; const float* pc;   // element of env 0 (pb, pc may be null)
+    int sa, sb, sc;                                        // floats per env
+    int kind;                                              // 0 scale * a, 1 a - b, 2 unscale(a, b, c), 3 quaternion difference
+    float scale;
+    int qk;                                                // kind 3: component
+};
+
 __global__ void k_full_obs(mdp_inhand_cfg_t cfg, const float* __restrict__ q, const float* __restrict__ qd,
                            const float* __restrict__ lower, const float* __restrict__ upper,
                            const float* __restrict__ obj, const float* __restrict__ origins,
@@ -130,50 +161,67 @@ __global__ void k_full_obs(mdp_inhand_cfg_t cfg, const float* __restrict__ q, co
                            const float* __restrict__ body, const int32_t* __restrict__ fingers,
                            const float* __restrict__ actions, int A, float* __restrict__ obs, int ld_obs, int O,
                            const float* __restrict__ link_xf, const float* __restrict__ link_vel) {
-    int D = cfg.num_dofs, F = cfg.num_fingertips, B = cfg.num_bodies;
-    int64_t total = (int64_t)cfg.num_envs * O;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t e = i / O;
-        int c = (int)(i - e * O);
-        const float* r = obj + 13 * e;
-        float v;
+    extern __shared__ __align__(16) unsigned char s_raw[];
+    FullObsCol* cols = reinterpret_cast<FullObsCol*>(s_raw);
+    const int D = cfg.num_dofs, F = cfg.num_fingertips, B = cfg.num_bodies;
+    for (int c = threadIdx.x; c < O; c += blockDim.x) {
+        FullObsCol d{obj, nullptr, nullptr, 13, 0, 0, 0, 1.0f, 0};
         int k = c;
         if (k < D) {
-            v = ih_unscale(q[e * D + k], lower[e * D + k], upper[e * D + k]);
+            d.pa = q + k; d.pb = lower + k; d.pc = upper + k; d.sa = d.sb = d.sc = D; d.kind = 2;
         } else if ((k -= D) < D) {
-            v = cfg.vel_obs_scale * qd[e * D + k];
+            d.pa = qd + k; d.sa = D; d.scale = cfg.vel_obs_scale;
         } else if ((k -= D) < 3) {
-            v = r[k] - origins[3 * e + k];  // object_pos
+            d.pa = obj + k; d.pb = origins + k; d.sb = 3; d.kind = 1;          // object_pos
         } else if ((k -= 3) < 4) {
-            v = r[3 + k];  // object_rot
+            d.pa = obj + 3 + k;                                                  // object_rot
         } else if ((k -= 4) < 3) {
-            v = r[7 + k];  // object_linvel
+            d.pa = obj + 7 + k;                                                  // object_linvel
         } else if ((k -= 3) < 3) {
-            v = cfg.vel_obs_scale * r[10 + k];
+            d.pa = obj + 10 + k; d.scale = cfg.vel_obs_scale;
         } else if ((k -= 3) < 3) {
-            v = in_hand[3 * e + k];
+            d.pa = in_hand + k; d.sa = 3;
         } else if ((k -= 3) < 4) {
-            v = goal_rot[4 * e + k];
+            d.pa = goal_rot + k; d.sa = 4;
         } else if ((k -= 4) < 4) {
-            v = get(quat_mul(ld4(r + 3), quat_conjugate(ld4(goal_rot + 4 * e))), k);
+            d.pa = obj + 3; d.pb = goal_rot; d.sb = 4; d.kind = 3; d.qk = k;
         } else if ((k -= 4) < 3 * F) {
             int f = k / 3, a = k - 3 * f;
             // body == nullptr: the fingertip rows come from the physics view's link buffers (xyzw transforms, (N,B,7) and
             // (N,B,6)) -- the values body_state_w would hold (articulation_data.py:323-337) without packing all B bodies
-            float p = body ? body[(e * B + fingers[f]) * 13 + a] : link_xf[(e * B + fingers[f]) * 7 + a];
-            v = p - origins[3 * e + a];
+            if (body) { d.pa = body + (int64_t)fingers[f] * 13 + a; d.sa = B * 13; }
+            else { d.pa = link_xf + (int64_t)fingers[f] * 7 + a; d.sa = B * 7; }
+            d.pb = origins + a; d.sb = 3; d.kind = 1;
         } else if ((k -= 3 * F) < 4 * F) {
             int f = k / 4, a = k - 4 * f;
-            v = body ? body[(e * B + fingers[f]) * 13 + 3 + a] : link_xf[(e * B + fingers[f]) * 7 + (a == 0 ? 6 : 2 + a)];
+            if (body) { d.pa = body + (int64_t)fingers[f] * 13 + 3 + a; d.sa = B * 13; }
+            else { d.pa = link_xf + (int64_t)fingers[f] * 7 + (a == 0 ? 6 : 2 + a); d.sa = B * 7; }
         } else if ((k -= 4 * F) < 6 * F) {
             int f = k / 6, a = k - 6 * f;
-            v = body ? body[(e * B + fingers[f]) * 13 + 7 + a] : link_vel[(e * B + fingers[f]) * 6 + a];
+            if (body) { d.pa = body + (int64_t)fingers[f] * 13 + 7 + a; d.sa = B * 13; }
+            else { d.pa = link_vel + (int64_t)fingers[f] * 6 + a; d.sa = B * 6; }
         } else {
             k -= 6 * F;
-            v = actions[e * A + k];
+            d.pa = actions + k; d.sa = A;
         }
-        obs[e * ld_obs + c] = v;
+        cols[c] = d;
+    }
+    __syncthreads();
+    const int64_t e0 = (int64_t)blockIdx.x * FULL_OBS_EPB;
+    const int64_t e1 = e0 + FULL_OBS_EPB < cfg.num_envs ? e0 + FULL_OBS_EPB : cfg.num_envs;
+    for (int c = threadIdx.x; c < O; c += blockDim.x) {
+        const FullObsCol d = cols[c];
+#pragma unroll 4
+        for (int64_t e = e0; e < e1; ++e) {
+            const float* pa = d.pa + e * d.sa;
+            const float va = *pa;
+            const float vb = (d.pb && d.kind != 3) ? d.pb[e * d.sb] : 0.0f;
+            const float vc = d.pc ? d.pc[e * d.sc] : 0.0f;
+            float v;
+            if (d.kind == 3) v = get(quat_mul(ld4(pa), quat_conjugate(ld4(d.pb + e * d.sb))), d.qk);
+            else v = d.kind == 0 ? d.scale * va : (d.kind == 1 ? va - vb : ih_unscale(va, vb, vc));
+            obs[e * ld_obs + c] = v;
+        }
     }
 }
 
@@ -298,9 +346,11 @@ extern "C" int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joi
                 "null pointer");
     int O = 2 * cfg->num_dofs + 13 + 11 + 13 * cfg->num_fingertips + action_dim;
     MDP_REQUIRE(ld_obs >= O, "obs buffer too narrow (%d < %d)", ld_obs, O);
-    int64_t total = (int64_t)cfg->num_envs * O;
-    if (total == 0) return MDP_OK;
-    hipLaunchKernelGGL(k_full_obs, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, joint_pos,
+    if (cfg->num_envs == 0) return MDP_OK;
+    const int threads = std::min(256, (O + 63) / 64 * 64);
+    const size_t lds = (size_t)O * sizeof(FullObsCol);
+    MDP_REQUIRE(lds <= 60 * 1024, "observation too wide for the column table (%d columns)", O);
+    hipLaunchKernelGGL(k_full_obs, dim3(grid_for(cfg->num_envs, FULL_OBS_EPB)), dim3(threads), lds, as_stream(stream), *cfg, joint_pos,
                        joint_vel, lower, upper, object_root_state, env_origins, in_hand_pos, goal_rot, body_state_w,
                        finger_bodies, actions, action_dim, obs, ld_obs, O, (const float*)nullptr, (const float*)nullptr);
     MDP_LAUNCH_CHECK();
@@ -318,9 +368,11 @@ extern "C" int mdp_inhand_full_obs_from_view(const mdp_inhand_cfg_t* cfg, const 
                 "null pointer");
     int O = 2 * cfg->num_dofs + 13 + 11 + 13 * cfg->num_fingertips + action_dim;
     MDP_REQUIRE(ld_obs >= O, "obs buffer too narrow (%d < %d)", ld_obs, O);
-    int64_t total = (int64_t)cfg->num_envs * O;
-    if (total == 0) return MDP_OK;
-    hipLaunchKernelGGL(k_full_obs, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, joint_pos,
+    if (cfg->num_envs == 0) return MDP_OK;
+    const int threads = std::min(256, (O + 63) / 64 * 64);
+    const size_t lds = (size_t)O * sizeof(FullObsCol);
+    MDP_REQUIRE(lds <= 60 * 1024, "observation too wide for the column table (%d columns)", O);
+    hipLaunchKernelGGL(k_full_obs, dim3(grid_for(cfg->num_envs, FULL_OBS_EPB)), dim3(threads), lds, as_stream(stream), *cfg, joint_pos,
                        joint_vel, lower, upper, object_root_state, env_origins, in_hand_pos, goal_rot,
                        (const float*)nullptr, finger_bodies, actions, action_dim, obs, ld_obs, O, link_transforms,
                        link_velocities);
