@@ -592,7 +592,9 @@ int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joint_pos, con
  * 293-380, inhand_manipulation_env.py:97-199): one launch each instead of a launch plus two to four small torch kernels.
  * Same arithmetic, same outputs as the calls above.
  *  _to        : also writes the actuated columns of the articulation's joint_pos_target (N, ld_target) --
- *               `self.hand.set_joint_position_target(self.cur_targets[:, actuated], joint_ids=actuated)` (:115-117).
+ *               `self.hand.set_joint_position_target(self.cur_targets[:, actuated], joint_ids=actuated)` (:115-117);
+ *               actions_copy (N, num_actuated; NULL = none): `self.actions = actions.clone()` of _pre_physics_step
+ *               (:94-95) written by the same launch (the first sub-step's call passes the caller's tensor as `actions`).
  *  dones_step : `episode_length_buf += 1` (direct_rl_env.py:343) first, then _get_dones written straight into
  *               reset_terminated / reset_time_outs, and reset_buf = terminated | time_outs (:344-346).
  *  rewards_step / finish_rewards_step : reset_goal_buf updated in place (:172); `partials` must be zero on entry and is
@@ -601,7 +603,7 @@ int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joint_pos, con
  *  full_obs_from_view : the fingertip rows are read from the physics view's link buffers ((N,B,7) xyzw transforms,
  *               (N,B,6) velocities: what body_state_w is assembled from, articulation_data.py:323-337) instead of a
  *               packed (N,B,13) body_state_w -- 5 of 26 bodies are used, the pack of all 26 was a third of the step. */
-int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const float* actions, const int32_t* actuated_idx,
+int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const float* actions, float* actions_copy, const int32_t* actuated_idx,
                                const float* lower, const float* upper, float* cur_targets, float* prev_targets,
                                float* joint_pos_target, int ld_target, void* stream);
 int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, const float* object_root_state, const float* env_origins,

@@ -22,7 +22,7 @@ MDP_DEV float rotation_distance(Q4 obj, Q4 target) {
 __global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ actions,
                                const int32_t* __restrict__ act_idx, const float* __restrict__ lower,
                                const float* __restrict__ upper, float* __restrict__ cur, float* __restrict__ prev,
-                               float* __restrict__ target, int ld_target) {
+                               float* __restrict__ target, int ld_target, float* __restrict__ actions_copy) {
     int64_t total = (int64_t)cfg.num_envs * cfg.num_actuated;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
@@ -31,7 +31,9 @@ __global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ a
         int j = act_idx[a];
         int64_t o = e * cfg.num_dofs + j;
         float lo = lower[o], hi = upper[o];
-        float t = ih_scale(actions[i], lo, hi);
+        const float act = actions[i];
+        if (actions_copy) actions_copy[i] = act;     // `self.actions = actions.clone()` (:94-95) rides along
+        float t = ih_scale(act, lo, hi);
         t = cfg.act_moving_average * t + (1.0f - cfg.act_moving_average) * prev[o];
         t = tmax(tmin(t, hi), lo);  // math.py:64-78 saturate
         cur[o] = t;
@@ -234,12 +236,12 @@ extern "C" int mdp_inhand_apply_action(const mdp_inhand_cfg_t* cfg, const float*
     int64_t total = (int64_t)cfg->num_envs * cfg->num_actuated;
     if (total == 0) return MDP_OK;
     hipLaunchKernelGGL(k_apply_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, actions,
-                       actuated_idx, lower, upper, cur_targets, prev_targets, (float*)nullptr, 0);
+                       actuated_idx, lower, upper, cur_targets, prev_targets, (float*)nullptr, 0, (float*)nullptr);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
 
-extern "C" int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const float* actions,
+extern "C" int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const float* actions, float* actions_copy,
                                           const int32_t* actuated_idx, const float* lower, const float* upper,
                                           float* cur_targets, float* prev_targets, float* joint_pos_target,
                                           int ld_target, void* stream) {
@@ -249,7 +251,8 @@ extern "C" int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const flo
     int64_t total = (int64_t)cfg->num_envs * cfg->num_actuated;
     if (total == 0) return MDP_OK;
     hipLaunchKernelGGL(k_apply_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, actions,
-                       actuated_idx, lower, upper, cur_targets, prev_targets, joint_pos_target, ld_target);
+                       actuated_idx, lower, upper, cur_targets, prev_targets, joint_pos_target, ld_target,
+                       actions_copy == actions ? (float*)nullptr : actions_copy);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -160,13 +160,20 @@ class InHandManipulationEnv:
     # -- DirectRLEnv hooks --------------------------------------------------------------------------------
     def _pre_physics_step(self, actions: torch.Tensor) -> None:
         """:94-95"""
+        if self.fused_step and actions.dtype == torch.float32 and actions.is_contiguous() and actions.shape == self.actions.shape:
+            self._actions_in = actions       # the first _apply_action launch of the step writes the copy
+            return
+        self._actions_in = None
         self.actions.copy_(actions)
 
     def _apply_action(self) -> None:
         """:97-117: scale -> moving average -> saturate on the actuated joints, targets handed to the articulation."""
         if self.fused_step:
             tgt = self.hand.joint_pos_target
-            L.check(L.lib.mdp_inhand_apply_action_to(C.byref(self._ccfg), L.ptr(self.actions), L.ptr(self._act_idx),
+            src = getattr(self, "_actions_in", None)
+            self._actions_in = None
+            L.check(L.lib.mdp_inhand_apply_action_to(C.byref(self._ccfg), L.ptr(src if src is not None else self.actions),
+                                                     L.ptr(self.actions) if src is not None else None, L.ptr(self._act_idx),
                                                      L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
                                                      L.ptr(self.cur_targets), L.ptr(self.prev_targets), L.ptr(tgt),
                                                      tgt.stride(0), L.stream()))

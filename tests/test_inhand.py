@@ -92,6 +92,7 @@ def test_gpu_inhand_vs_reference_fixture(golden, device, n, fused):
     # _apply_action
     env.prev_targets.copy_(to_dev(G[p + "prev"], device))
     env._apply_action()
+    np.testing.assert_array_equal(to_np(env.actions), G[p + "actions"])   # the clone of _pre_physics_step (fused: same launch)
     assert_close(to_np(env.cur_targets), G[p + "cur_out"])
     assert_close(to_np(env.prev_targets), G[p + "prev_out"])
     assert_close(to_np(env.hand.joint_pos_target), G[p + "cur_out"])
