@@ -597,19 +597,26 @@ int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joint_pos, con
  *               (:94-95) written by the same launch (the first sub-step's call passes the caller's tensor as `actions`).
  *  dones_step : `episode_length_buf += 1` (direct_rl_env.py:343) first, then _get_dones written straight into
  *               reset_terminated / reset_time_outs, and reset_buf = terminated | time_outs (:344-346).
+ *               With object_transforms / object_velocities (the object's physics view buffers) the launch first
+ *               assembles object_root_state (N,13) from them -- RigidObjectData.root_state_w, the cat of
+ *               articulation_data.py:264-279 that mdp_state_pack does -- stores it for the launches behind it and works
+ *               from registers; without them object_root_state is an input as in mdp_inhand_dones.
  *  rewards_step / finish_rewards_step : reset_goal_buf updated in place (:172); `partials` must be zero on entry and is
  *               left zeroed by finish_rewards_step (no memset node per step); an all-reduce of `partials` may sit
  *               between the two calls as above.
  *  full_obs_from_view : the fingertip rows are read from the physics view's link buffers ((N,B,7) xyzw transforms,
  *               (N,B,6) velocities: what body_state_w is assembled from, articulation_data.py:323-337) instead of a
- *               packed (N,B,13) body_state_w -- 5 of 26 bodies are used, the pack of all 26 was a third of the step. */
+ *               packed (N,B,13) body_state_w -- 5 of 26 bodies are used, the pack of all 26 was a third of the step.
+ *               With partials / consecutive_successes the launch also does what finish_rewards_step does (the reward
+ *               launch of the step, and an all-reduce of `partials` if there is one, are in front of it in the stream). */
 int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const float* actions, float* actions_copy, const int32_t* actuated_idx,
                                const float* lower, const float* upper, float* cur_targets, float* prev_targets,
                                float* joint_pos_target, int ld_target, void* stream);
-int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, const float* object_root_state, const float* env_origins,
+int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, float* object_root_state, const float* env_origins,
                           const float* in_hand_pos, const float* goal_rot, const float* successes,
                           int64_t* episode_length_buf, uint8_t* reset_terminated, uint8_t* reset_time_outs,
-                          uint8_t* reset_buf, void* stream);
+                          uint8_t* reset_buf, const float* object_transforms /* (N,7) xyzw or NULL */,
+                          const float* object_velocities /* (N,6) or NULL */, void* stream);
 int mdp_inhand_rewards_step(const mdp_inhand_cfg_t* cfg, const float* object_root_state, const float* env_origins,
                             const float* in_hand_pos, const float* goal_rot, const float* actions,
                             const uint8_t* reset_buf, uint8_t* reset_goal_buf, float* successes, float* reward,
@@ -621,7 +628,9 @@ int mdp_inhand_full_obs_from_view(const mdp_inhand_cfg_t* cfg, const float* join
                                   const float* env_origins, const float* in_hand_pos, const float* goal_rot,
                                   const float* link_transforms /* (N,B,7) xyzw */,
                                   const float* link_velocities /* (N,B,6) */, const int32_t* finger_bodies,
-                                  const float* actions, int action_dim, float* obs, int ld_obs, void* stream);
+                                  const float* actions, int action_dim, float* obs, int ld_obs,
+                                  double* partials /* or NULL */, float* consecutive_successes /* or NULL */,
+                                  void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Statistics for the cross-GPU reductions: per-rank partials in fp64.

@@ -44,15 +44,30 @@ __global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ a
 }
 
 // :179-199
-__global__ void k_dones(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, const float* __restrict__ origins,
+__global__ void k_dones(mdp_inhand_cfg_t cfg, const float* obj, const float* __restrict__ origins,
                         const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
                         const float* __restrict__ successes, int64_t* __restrict__ ep_len,
                         uint8_t* __restrict__ out_of_reach, uint8_t* __restrict__ time_out, int increment,
-                        uint8_t* __restrict__ reset_buf) {
+                        uint8_t* __restrict__ reset_buf, const float* __restrict__ obj_xf,
+                        const float* __restrict__ obj_vel, float* obj_out) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= cfg.num_envs) return;
     if (increment) ep_len[e] += 1;          // direct_rl_env.py:343 episode_length_buf += 1, ahead of _get_dones
+    float row[13];
     const float* r = obj + 13 * (int64_t)e;
+    if (obj_xf) {
+        // RigidObjectData.root_state_w of this env (cat(pose with xyzw -> wxyz, velocity), as mdp_state_pack) assembled
+        // here, stored for the kernels behind this one and used from registers
+        const float* x = obj_xf + 7 * (int64_t)e;
+        const float* w = obj_vel + 6 * (int64_t)e;
+        row[0] = x[0]; row[1] = x[1]; row[2] = x[2]; row[3] = x[6]; row[4] = x[3]; row[5] = x[4]; row[6] = x[5];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) row[7 + k] = w[k];
+        float* o = obj_out + 13 * (int64_t)e;
+#pragma unroll
+        for (int k = 0; k < 13; ++k) o[k] = row[k];
+        r = row;
+    }
     V3 pos{r[0] - origins[3 * e], r[1] - origins[3 * e + 1], r[2] - origins[3 * e + 2]};
     V3 d{pos.x - in_hand[3 * e], pos.y - in_hand[3 * e + 1], pos.z - in_hand[3 * e + 2]};
     float goal_dist = norm3(d);
@@ -162,8 +177,16 @@ __global__ void k_full_obs(mdp_inhand_cfg_t cfg, const float* __restrict__ q, co
                            const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
                            const float* __restrict__ body, const int32_t* __restrict__ fingers,
                            const float* __restrict__ actions, int A, float* __restrict__ obs, int ld_obs, int O,
-                           const float* __restrict__ link_xf, const float* __restrict__ link_vel) {
+                           const float* __restrict__ link_xf, const float* __restrict__ link_vel,
+                           double* __restrict__ partials, float* __restrict__ cons) {
     extern __shared__ __align__(16) unsigned char s_raw[];
+    if (partials && blockIdx.x == 0 && threadIdx.x == 0) {
+        // mdp_inhand_finish_rewards_step riding along: the reward launch in front of this one left the two sums
+        const float num_resets = (float)partials[0];
+        const float finished = (float)partials[1];
+        if (num_resets > 0.0f) cons[0] = cfg.av_factor * finished / num_resets + (1.0f - cfg.av_factor) * cons[0];
+        partials[0] = 0.0; partials[1] = 0.0;
+    }
     FullObsCol* cols = reinterpret_cast<FullObsCol*>(s_raw);
     const int D = cfg.num_dofs, F = cfg.num_fingertips, B = cfg.num_bodies;
     for (int c = threadIdx.x; c < O; c += blockDim.x) {
@@ -266,22 +289,27 @@ extern "C" int mdp_inhand_dones(const mdp_inhand_cfg_t* cfg, const float* object
     if (cfg->num_envs == 0) return MDP_OK;
     hipLaunchKernelGGL(k_dones, dim3(grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), *cfg,
                        object_root_state, env_origins, in_hand_pos, goal_rot, successes, episode_length_buf,
-                       out_of_reach, time_out, 0, (uint8_t*)nullptr);
+                       out_of_reach, time_out, 0, (uint8_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       (float*)nullptr);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
 
-extern "C" int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, const float* object_root_state,
+extern "C" int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, float* object_root_state,
                                      const float* env_origins, const float* in_hand_pos, const float* goal_rot,
                                      const float* successes, int64_t* episode_length_buf, uint8_t* reset_terminated,
-                                     uint8_t* reset_time_outs, uint8_t* reset_buf, void* stream) {
+                                     uint8_t* reset_time_outs, uint8_t* reset_buf, const float* object_transforms,
+                                     const float* object_velocities, void* stream) {
     MDP_REQUIRE(cfg && object_root_state && env_origins && in_hand_pos && goal_rot && successes &&
                     episode_length_buf && reset_terminated && reset_time_outs && reset_buf,
                 "null pointer");
+    MDP_REQUIRE((object_transforms == nullptr) == (object_velocities == nullptr),
+                "object_transforms and object_velocities go together");
     if (cfg->num_envs == 0) return MDP_OK;
     hipLaunchKernelGGL(k_dones, dim3(grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), *cfg,
                        object_root_state, env_origins, in_hand_pos, goal_rot, successes, episode_length_buf,
-                       reset_terminated, reset_time_outs, 1, reset_buf);
+                       reset_terminated, reset_time_outs, 1, reset_buf, object_transforms, object_velocities,
+                       object_root_state);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
@@ -355,7 +383,8 @@ extern "C" int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joi
     MDP_REQUIRE(lds <= 60 * 1024, "observation too wide for the column table (%d columns)", O);
     hipLaunchKernelGGL(k_full_obs, dim3(grid_for(cfg->num_envs, FULL_OBS_EPB)), dim3(threads), lds, as_stream(stream), *cfg, joint_pos,
                        joint_vel, lower, upper, object_root_state, env_origins, in_hand_pos, goal_rot, body_state_w,
-                       finger_bodies, actions, action_dim, obs, ld_obs, O, (const float*)nullptr, (const float*)nullptr);
+                       finger_bodies, actions, action_dim, obs, ld_obs, O, (const float*)nullptr, (const float*)nullptr,
+                       (double*)nullptr, (float*)nullptr);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }
@@ -365,10 +394,12 @@ extern "C" int mdp_inhand_full_obs_from_view(const mdp_inhand_cfg_t* cfg, const 
                                              const float* env_origins, const float* in_hand_pos, const float* goal_rot,
                                              const float* link_transforms, const float* link_velocities,
                                              const int32_t* finger_bodies, const float* actions, int action_dim,
-                                             float* obs, int ld_obs, void* stream) {
+                                             float* obs, int ld_obs, double* partials, float* consecutive_successes,
+                                             void* stream) {
     MDP_REQUIRE(cfg && joint_pos && joint_vel && lower && upper && object_root_state && env_origins && in_hand_pos &&
                     goal_rot && link_transforms && link_velocities && finger_bodies && actions && obs,
                 "null pointer");
+    MDP_REQUIRE((partials == nullptr) == (consecutive_successes == nullptr), "partials and consecutive_successes go together");
     int O = 2 * cfg->num_dofs + 13 + 11 + 13 * cfg->num_fingertips + action_dim;
     MDP_REQUIRE(ld_obs >= O, "obs buffer too narrow (%d < %d)", ld_obs, O);
     if (cfg->num_envs == 0) return MDP_OK;
@@ -378,7 +409,7 @@ extern "C" int mdp_inhand_full_obs_from_view(const mdp_inhand_cfg_t* cfg, const 
     hipLaunchKernelGGL(k_full_obs, dim3(grid_for(cfg->num_envs, FULL_OBS_EPB)), dim3(threads), lds, as_stream(stream), *cfg, joint_pos,
                        joint_vel, lower, upper, object_root_state, env_origins, in_hand_pos, goal_rot,
                        (const float*)nullptr, finger_bodies, actions, action_dim, obs, ld_obs, O, link_transforms,
-                       link_velocities);
+                       link_velocities, partials, consecutive_successes);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

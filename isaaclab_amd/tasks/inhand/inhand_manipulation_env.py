@@ -128,6 +128,7 @@ class InHandManipulationEnv:
         # the last step's sums behind -- switching forms starts from zero
         self._fused_step = bool(value)
         self._partials.zero_()
+        self._finish_pending = False
 
     # -- properties (direct_rl_env.py:228-248) ----------------------------------------------------------
     @property
@@ -205,14 +206,25 @@ class InHandManipulationEnv:
     def _dones_step(self) -> None:
         """direct_rl_env.py:343-346 as one launch: ``episode_length_buf += 1``, ``_get_dones`` written straight into
         ``reset_terminated`` / ``reset_time_outs``, ``reset_buf = reset_terminated | reset_time_outs``."""
-        L.check(L.lib.mdp_inhand_dones_step(C.byref(self._ccfg), L.ptr(self.object.data.root_state_w),
+        od = self.object.data
+        xf = vel = None
+        if od._root_state_w.timestamp < od._sim_timestamp:
+            # the object's root_state_w is stale: this launch assembles it from the view (what the property's pack
+            # launch would do) and the rewards / observations behind it read the buffer it leaves
+            xf, vel = od._root_physx_view.get_transforms(), od._root_physx_view.get_root_velocities()
+            state = od._root_state_w.data
+            od._root_state_w.timestamp = od._sim_timestamp
+        else:
+            state = od.root_state_w
+        L.check(L.lib.mdp_inhand_dones_step(C.byref(self._ccfg), L.ptr(state),
                                             L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
                                             L.ptr(self.successes), L.ptr(self.episode_length_buf),
                                             L.ptr(self.reset_terminated), L.ptr(self.reset_time_outs),
-                                            L.ptr(self.reset_buf), L.stream()))
+                                            L.ptr(self.reset_buf), L.ptr(xf), L.ptr(vel), L.stream()))
 
-    def _get_rewards(self) -> torch.Tensor:
-        """:140-177 / compute_rewards :377-433"""
+    def _get_rewards(self, defer_finish: bool = False) -> torch.Tensor:
+        """:140-177 / compute_rewards :377-433.  ``defer_finish`` (only ``step()`` passes it): the moving average of
+        ``consecutive_successes`` is folded into the observation launch that follows in the same step."""
         if self.fused_step:
             L.check(L.lib.mdp_inhand_rewards_step(C.byref(self._ccfg), L.ptr(self.object.data.root_state_w),
                                                   L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos),
@@ -223,8 +235,11 @@ class InHandManipulationEnv:
                 import torch.distributed as dist
 
                 dist.all_reduce(self._partials, group=self.group)
-            L.check(L.lib.mdp_inhand_finish_rewards_step(C.byref(self._ccfg), L.ptr(self._partials),
-                                                         L.ptr(self.consecutive_successes), L.stream()))
+            if defer_finish:
+                self._finish_pending = True
+            else:
+                L.check(L.lib.mdp_inhand_finish_rewards_step(C.byref(self._ccfg), L.ptr(self._partials),
+                                                             L.ptr(self.consecutive_successes), L.stream()))
             if "log" not in self.extras:
                 self.extras["log"] = dict()
             # the mean of the one-element buffer (:431) is that element: a view, no reduction kernel
@@ -251,12 +266,15 @@ class InHandManipulationEnv:
         """:298-322"""
         if self.fused_step:
             view = self.hand.root_physx_view
+            finish, self._finish_pending = getattr(self, "_finish_pending", False), False
             L.check(L.lib.mdp_inhand_full_obs_from_view(
                 C.byref(self._ccfg), L.ptr(self.hand.data.joint_pos), L.ptr(self.hand.data.joint_vel),
                 L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits), L.ptr(self.object.data.root_state_w),
                 L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
                 L.ptr(view.get_link_transforms()), L.ptr(view.get_link_velocities()), L.ptr(self._fingers),
-                L.ptr(self.actions), self.cfg.action_space, L.ptr(self._obs), self._obs.stride(0), L.stream()))
+                L.ptr(self.actions), self.cfg.action_space, L.ptr(self._obs), self._obs.stride(0),
+                L.ptr(self._partials) if finish else None, L.ptr(self.consecutive_successes) if finish else None,
+                L.stream()))
             return self._obs
         L.check(L.lib.mdp_inhand_full_obs(C.byref(self._ccfg), L.ptr(self.hand.data.joint_pos),
                                           L.ptr(self.hand.data.joint_vel), L.ptr(self.hand_dof_lower_limits),
@@ -313,7 +331,7 @@ class InHandManipulationEnv:
             self.reset_terminated[:] = terminated
             self.reset_time_outs[:] = time_outs
             torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
-        self.reward_buf = self._get_rewards()
+        self.reward_buf = self._get_rewards(defer_finish=self.fused_step)
         if reset_goals:                                    # :172-175 (host sync, like the reference)
             goal_env_ids = self.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)
             if len(goal_env_ids) > 0:
