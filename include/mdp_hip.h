@@ -612,6 +612,23 @@ int mdp_inhand_full_obs(const mdp_inhand_cfg_t* cfg, const float* joint_pos, con
 int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const float* actions, float* actions_copy, const int32_t* actuated_idx,
                                const float* lower, const float* upper, float* cur_targets, float* prev_targets,
                                float* joint_pos_target, int ld_target, void* stream);
+/* apply_action_to with the PREVIOUS sub-step's `self.hand.data.update(dt)` (direct_rl_env.py:330-339, articulation_data.py:
+ * 77-82: the mdp_scene_update descriptor) on blocks of the same launch -- the new targets do not depend on it. */
+int mdp_inhand_apply_action_to_with_update(const mdp_inhand_cfg_t* cfg, const float* actions, float* actions_copy,
+                                           const int32_t* actuated_idx, const float* lower, const float* upper,
+                                           float* cur_targets, float* prev_targets, float* joint_pos_target, int ld_target,
+                                           const mdp_scene_update_t* update, float dt, void* stream);
+/* direct_rl_env.py:343-349 as ONE launch: dones_step followed, per env and in the same thread, by rewards_step (which takes
+ * the env's reset flag and the object's state from registers); `update` (or NULL): the last sub-step's
+ * `self.hand.data.update(dt)` on blocks of the same launch (neither the dones nor the rewards read the hand).  Same
+ * buffers and values as mdp_inhand_dones_step + mdp_inhand_rewards_step; `partials` as for rewards_step. */
+int mdp_inhand_dones_rewards_step(const mdp_inhand_cfg_t* cfg, float* object_root_state, const float* env_origins,
+                                  const float* in_hand_pos, const float* goal_rot, float* successes,
+                                  int64_t* episode_length_buf, uint8_t* reset_terminated, uint8_t* reset_time_outs,
+                                  uint8_t* reset_buf, const float* object_transforms /* (N,7) xyzw or NULL */,
+                                  const float* object_velocities /* (N,6) or NULL */, const float* actions,
+                                  uint8_t* reset_goal_buf, float* reward, double* partials,
+                                  const mdp_scene_update_t* update /* or NULL */, float dt, void* stream);
 int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, float* object_root_state, const float* env_origins,
                           const float* in_hand_pos, const float* goal_rot, const float* successes,
                           int64_t* episode_length_buf, uint8_t* reset_terminated, uint8_t* reset_time_outs,

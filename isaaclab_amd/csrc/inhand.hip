@@ -2,6 +2,7 @@
 // Reference: TASKS/direct/inhand_manipulation/inhand_manipulation_env.py:97-117,179-199,262-433
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
+#include "scene_update_device.hpp"
 
 using namespace mdp;
 
@@ -18,14 +19,14 @@ MDP_DEV float rotation_distance(Q4 obj, Q4 target) {
     return 2.0f * asinf(tclamp_max(n, 1.0f));
 }
 
-// :97-117, one thread per (env, actuated joint)
-__global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ actions,
-                               const int32_t* __restrict__ act_idx, const float* __restrict__ lower,
-                               const float* __restrict__ upper, float* __restrict__ cur, float* __restrict__ prev,
-                               float* __restrict__ target, int ld_target, float* __restrict__ actions_copy) {
+// :97-117, one thread per (env, actuated joint); block `b` of `nb`
+__device__ __forceinline__ void apply_action_blocks(const mdp_inhand_cfg_t& cfg, const float* __restrict__ actions,
+                                                    const int32_t* __restrict__ act_idx, const float* __restrict__ lower,
+                                                    const float* __restrict__ upper, float* __restrict__ cur,
+                                                    float* __restrict__ prev, float* __restrict__ target, int ld_target,
+                                                    float* __restrict__ actions_copy, unsigned b, unsigned nb) {
     int64_t total = (int64_t)cfg.num_envs * cfg.num_actuated;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = b * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)nb * blockDim.x) {
         int64_t e = i / cfg.num_actuated;
         int a = (int)(i - e * cfg.num_actuated);
         int j = act_idx[a];
@@ -43,18 +44,40 @@ __global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ a
     }
 }
 
-// :179-199
-__global__ void k_dones(mdp_inhand_cfg_t cfg, const float* obj, const float* __restrict__ origins,
-                        const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
-                        const float* __restrict__ successes, int64_t* __restrict__ ep_len,
-                        uint8_t* __restrict__ out_of_reach, uint8_t* __restrict__ time_out, int increment,
-                        uint8_t* __restrict__ reset_buf, const float* __restrict__ obj_xf,
-                        const float* __restrict__ obj_vel, float* obj_out) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= cfg.num_envs) return;
+__global__ void k_apply_action(mdp_inhand_cfg_t cfg, const float* __restrict__ actions,
+                               const int32_t* __restrict__ act_idx, const float* __restrict__ lower,
+                               const float* __restrict__ upper, float* __restrict__ cur, float* __restrict__ prev,
+                               float* __restrict__ target, int ld_target, float* __restrict__ actions_copy) {
+    apply_action_blocks(cfg, actions, act_idx, lower, upper, cur, prev, target, ld_target, actions_copy, blockIdx.x, gridDim.x);
+}
+
+// The same with the scene update of the PREVIOUS sub-step in front of the grid (`hand.data.update(dt)` after sim.step,
+// direct_rl_env.py:330-339): the targets of this sub-step do not depend on it, so both go in one launch
+__global__ void __launch_bounds__(256) k_apply_action_upd(mdp_inhand_cfg_t cfg, const float* __restrict__ actions,
+                                                          const int32_t* __restrict__ act_idx,
+                                                          const float* __restrict__ lower, const float* __restrict__ upper,
+                                                          float* __restrict__ cur, float* __restrict__ prev,
+                                                          float* __restrict__ target, int ld_target,
+                                                          float* __restrict__ actions_copy, mdp_scene_update_t upd, float dt,
+                                                          unsigned upd_total, unsigned nb_root, unsigned nb_joint,
+                                                          unsigned nb_contact, int upd_envs) {
+    if (blockIdx.x < upd_total) {
+        scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
+        return;
+    }
+    apply_action_blocks(cfg, actions, act_idx, lower, upper, cur, prev, target, ld_target, actions_copy,
+                        blockIdx.x - upd_total, gridDim.x - upd_total);
+}
+
+// :179-199 for env e; returns the env's reset flag (direct_rl_env.py:346) and leaves the object's root state in row[13]
+__device__ __forceinline__ uint8_t dones_env(const mdp_inhand_cfg_t& cfg, int e, const float* obj,
+                                             const float* __restrict__ origins, const float* __restrict__ in_hand,
+                                             const float* __restrict__ goal_rot, const float* successes,
+                                             int64_t* __restrict__ ep_len, uint8_t* __restrict__ out_of_reach,
+                                             uint8_t* __restrict__ time_out, int increment, uint8_t* __restrict__ reset_buf,
+                                             const float* __restrict__ obj_xf, const float* __restrict__ obj_vel,
+                                             float* obj_out, float* row) {
     if (increment) ep_len[e] += 1;          // direct_rl_env.py:343 episode_length_buf += 1, ahead of _get_dones
-    float row[13];
-    const float* r = obj + 13 * (int64_t)e;
     if (obj_xf) {
         // RigidObjectData.root_state_w of this env (cat(pose with xyzw -> wxyz, velocity), as mdp_state_pack) assembled
         // here, stored for the kernels behind this one and used from registers
@@ -66,8 +89,12 @@ __global__ void k_dones(mdp_inhand_cfg_t cfg, const float* obj, const float* __r
         float* o = obj_out + 13 * (int64_t)e;
 #pragma unroll
         for (int k = 0; k < 13; ++k) o[k] = row[k];
-        r = row;
+    } else {
+        const float* src = obj + 13 * (int64_t)e;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) row[k] = src[k];      // position + orientation: all this and the rewards read
     }
+    const float* r = row;
     V3 pos{r[0] - origins[3 * e], r[1] - origins[3 * e + 1], r[2] - origins[3 * e + 2]};
     V3 d{pos.x - in_hand[3 * e], pos.y - in_hand[3 * e + 1], pos.z - in_hand[3 * e + 2]};
     float goal_dist = norm3(d);
@@ -81,52 +108,67 @@ __global__ void k_dones(mdp_inhand_cfg_t cfg, const float* obj, const float* __r
     }
     bool to = len >= cfg.max_episode_length - 1;
     time_out[e] = (to || max_succ) ? 1 : 0;
-    if (reset_buf) reset_buf[e] = (goal_dist >= cfg.fall_dist || to || max_succ) ? 1 : 0;   // direct_rl_env.py:346
+    const uint8_t reset = (goal_dist >= cfg.fall_dist || to || max_succ) ? 1 : 0;   // direct_rl_env.py:346
+    if (reset_buf) reset_buf[e] = reset;
+    return reset;
 }
 
-// :377-433 per-env part; cross-env sums accumulated per block then atomically in fp64
-__global__ void k_rewards(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, const float* __restrict__ origins,
-                          const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
-                          const float* __restrict__ actions, const uint8_t* __restrict__ reset_buf,
-                          const uint8_t* __restrict__ reset_goal_buf, float* __restrict__ successes,
-                          float* __restrict__ reward, uint8_t* __restrict__ goal_resets,
-                          double* __restrict__ partials) {
+__global__ void k_dones(mdp_inhand_cfg_t cfg, const float* obj, const float* __restrict__ origins,
+                        const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
+                        const float* __restrict__ successes, int64_t* __restrict__ ep_len,
+                        uint8_t* __restrict__ out_of_reach, uint8_t* __restrict__ time_out, int increment,
+                        uint8_t* __restrict__ reset_buf, const float* __restrict__ obj_xf,
+                        const float* __restrict__ obj_vel, float* obj_out) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
-    double my_resets = 0.0, my_succ = 0.0;
-    if (e < cfg.num_envs) {
-        const float* r = obj + 13 * (int64_t)e;
-        V3 pos{r[0] - origins[3 * e], r[1] - origins[3 * e + 1], r[2] - origins[3 * e + 2]};
-        V3 d{pos.x - in_hand[3 * e], pos.y - in_hand[3 * e + 1], pos.z - in_hand[3 * e + 2]};
-        float goal_dist = norm3(d);
-        float rot_dist = rotation_distance(ld4(r + 3), ld4(goal_rot + 4 * (int64_t)e));
-        float dist_rew = goal_dist * cfg.dist_reward_scale;
-        float rot_rew = 1.0f / (fabsf(rot_dist) + cfg.rot_eps) * cfg.rot_reward_scale;
-        float ap = 0.0f;
-        int A = cfg.num_actuated;
-        const float* arow = actions + (int64_t)e * A;
-        if ((A & 3) == 0 && ((uintptr_t)actions & 15) == 0) {      // same sum order, four columns per load
-            for (int k = 0; k < A; k += 4) {
-                const float4 a4 = *reinterpret_cast<const float4*>(arow + k);
-                ap += a4.x * a4.x; ap += a4.y * a4.y; ap += a4.z * a4.z; ap += a4.w * a4.w;
-            }
-        } else {
-            for (int k = 0; k < A; ++k) { float a = arow[k]; ap += a * a; }
+    if (e >= cfg.num_envs) return;
+    float row[13];
+    dones_env(cfg, e, obj, origins, in_hand, goal_rot, successes, ep_len, out_of_reach, time_out, increment, reset_buf,
+              obj_xf, obj_vel, obj_out, row);
+}
+
+// :377-433 per-env part for env e (r = the object's root state: position + orientation are read); cross-env sums are
+// accumulated per block, then atomically in fp64
+__device__ __forceinline__ void rewards_env(const mdp_inhand_cfg_t& cfg, int e, const float* r,
+                                            const float* __restrict__ origins, const float* __restrict__ in_hand,
+                                            const float* __restrict__ goal_rot, const float* __restrict__ actions,
+                                            uint8_t reset_flag, const uint8_t* reset_goal_buf,
+                                            float* successes, float* __restrict__ reward,
+                                            uint8_t* goal_resets, double& my_resets, double& my_succ) {
+    V3 pos{r[0] - origins[3 * e], r[1] - origins[3 * e + 1], r[2] - origins[3 * e + 2]};
+    V3 d{pos.x - in_hand[3 * e], pos.y - in_hand[3 * e + 1], pos.z - in_hand[3 * e + 2]};
+    float goal_dist = norm3(d);
+    float rot_dist = rotation_distance(ld4(r + 3), ld4(goal_rot + 4 * (int64_t)e));
+    float dist_rew = goal_dist * cfg.dist_reward_scale;
+    float rot_rew = 1.0f / (fabsf(rot_dist) + cfg.rot_eps) * cfg.rot_reward_scale;
+    float ap = 0.0f;
+    int A = cfg.num_actuated;
+    const float* arow = actions + (int64_t)e * A;
+    if ((A & 3) == 0 && ((uintptr_t)actions & 15) == 0) {      // same sum order, four columns per load
+        for (int k = 0; k < A; k += 4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(arow + k);
+            ap += a4.x * a4.x; ap += a4.y * a4.y; ap += a4.z * a4.z; ap += a4.w * a4.w;
         }
-        float rew = (dist_rew + rot_rew) + ap * cfg.action_penalty_scale;
-        uint8_t gr = (fabsf(rot_dist) <= cfg.success_tolerance) ? 1 : reset_goal_buf[e];
-        float succ = successes[e] + (float)gr;
-        if (gr == 1) rew = rew + cfg.reach_goal_bonus;
-        bool fell = goal_dist >= cfg.fall_dist;
-        if (fell) rew = rew + cfg.fall_penalty;
-        uint8_t resets = fell ? 1 : reset_buf[e];
-        successes[e] = succ;
-        reward[e] = rew;
-        goal_resets[e] = gr;
-        my_resets = (double)resets;
-        my_succ = (double)(succ * (float)resets);
+    } else {
+        for (int k = 0; k < A; ++k) { float a = arow[k]; ap += a * a; }
     }
-    // wave reduction, the block's waves through LDS, then one fp64 atomic pair per block (both sums are sums of
-    // integer-valued terms: exact in any order); all of them land on the same two words, so fewer is faster
+    float rew = (dist_rew + rot_rew) + ap * cfg.action_penalty_scale;
+    uint8_t gr = (fabsf(rot_dist) <= cfg.success_tolerance) ? 1 : reset_goal_buf[e];
+    float succ = successes[e] + (float)gr;
+    if (gr == 1) rew = rew + cfg.reach_goal_bonus;
+    bool fell = goal_dist >= cfg.fall_dist;
+    if (fell) rew = rew + cfg.fall_penalty;
+    uint8_t resets = fell ? 1 : reset_flag;
+    successes[e] = succ;
+    reward[e] = rew;
+    goal_resets[e] = gr;
+    my_resets = (double)resets;
+    my_succ = (double)(succ * (float)resets);
+}
+
+// wave reduction, the block's waves through LDS, then one fp64 atomic pair per block (both sums are sums of
+// integer-valued terms: exact in any order); all of them land on the same two words, so fewer is faster.
+// Every thread of the block must call it.
+__device__ __forceinline__ void rewards_block_sums(double my_resets, double my_succ, double* __restrict__ partials) {
     __shared__ double s_part[2][16];
     for (int off = 32; off > 0; off >>= 1) {
         my_resets += __shfl_down(my_resets, off);
@@ -143,6 +185,48 @@ __global__ void k_rewards(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, c
             atomicAdd(&partials[1], q);
         }
     }
+}
+
+__global__ void k_rewards(mdp_inhand_cfg_t cfg, const float* __restrict__ obj, const float* __restrict__ origins,
+                          const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
+                          const float* __restrict__ actions, const uint8_t* __restrict__ reset_buf,
+                          const uint8_t* reset_goal_buf, float* __restrict__ successes,
+                          float* __restrict__ reward, uint8_t* goal_resets, double* __restrict__ partials) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double my_resets = 0.0, my_succ = 0.0;
+    if (e < cfg.num_envs)
+        rewards_env(cfg, e, obj + 13 * (int64_t)e, origins, in_hand, goal_rot, actions, reset_buf[e], reset_goal_buf,
+                    successes, reward, goal_resets, my_resets, my_succ);
+    rewards_block_sums(my_resets, my_succ, partials);
+}
+
+// direct_rl_env.py:343-349 in one launch: the last sub-step's `hand.data.update(dt)` on blocks in front of the grid (nothing
+// below reads the hand), then per env `episode_length_buf += 1`, _get_dones, reset_buf, _get_rewards -- the rewards take
+// the env's reset flag and the object's state from the registers of the thread that just produced them
+__global__ void __launch_bounds__(256) k_dones_rewards(mdp_inhand_cfg_t cfg, float* obj, const float* __restrict__ origins,
+                                                       const float* __restrict__ in_hand, const float* __restrict__ goal_rot,
+                                                       float* successes, int64_t* __restrict__ ep_len,
+                                                       uint8_t* __restrict__ out_of_reach, uint8_t* __restrict__ time_out,
+                                                       uint8_t* __restrict__ reset_buf, const float* __restrict__ obj_xf,
+                                                       const float* __restrict__ obj_vel, const float* __restrict__ actions,
+                                                       uint8_t* reset_goal_buf, float* __restrict__ reward,
+                                                       double* __restrict__ partials, mdp_scene_update_t upd, float dt,
+                                                       unsigned upd_total, unsigned nb_root, unsigned nb_joint,
+                                                       unsigned nb_contact, int upd_envs) {
+    if (blockIdx.x < upd_total) {
+        scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
+        return;
+    }
+    int e = (blockIdx.x - upd_total) * blockDim.x + threadIdx.x;
+    double my_resets = 0.0, my_succ = 0.0;
+    if (e < cfg.num_envs) {
+        float row[13];
+        const uint8_t reset = dones_env(cfg, e, obj, origins, in_hand, goal_rot, successes, ep_len, out_of_reach, time_out,
+                                        1, reset_buf, obj_xf, obj_vel, obj, row);
+        rewards_env(cfg, e, row, origins, in_hand, goal_rot, actions, reset, reset_goal_buf, successes, reward,
+                    reset_goal_buf, my_resets, my_succ);
+    }
+    rewards_block_sums(my_resets, my_succ, partials);
 }
 
 __global__ void k_finish_rewards(mdp_inhand_cfg_t cfg, const double* __restrict__ partials,
@@ -162,7 +246,10 @@ __global__ void k_finish_rewards(mdp_inhand_cfg_t cfg, const double* __restrict_
 // and a store -- with a flat 64-bit index per element the division and the branch chain were ~200 vector instructions
 // per element and the kernel was issue-bound (23 us for 20 MB).  v = scale * a | a - b | unscale(a, b, c) | one
 // component of the quaternion difference; 1.0f * a == a bit for bit, so plain copies share the scaled form.
-constexpr int FULL_OBS_EPB = 8;
+#ifndef MDP_FULL_OBS_EPB
+#define MDP_FULL_OBS_EPB 8
+#endif
+constexpr int FULL_OBS_EPB = MDP_FULL_OBS_EPB;
 struct FullObsCol {
     const float* pa; const float* pb; const float* pc;   // element of env 0 (pb, pc may be null)
     int sa, sb, sc;                                        // floats per env
@@ -276,6 +363,61 @@ extern "C" int mdp_inhand_apply_action_to(const mdp_inhand_cfg_t* cfg, const flo
     hipLaunchKernelGGL(k_apply_action, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg, actions,
                        actuated_idx, lower, upper, cur_targets, prev_targets, joint_pos_target, ld_target,
                        actions_copy == actions ? (float*)nullptr : actions_copy);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_apply_action_to_with_update(const mdp_inhand_cfg_t* cfg, const float* actions,
+                                                      float* actions_copy, const int32_t* actuated_idx,
+                                                      const float* lower, const float* upper, float* cur_targets,
+                                                      float* prev_targets, float* joint_pos_target, int ld_target,
+                                                      const mdp_scene_update_t* update, float dt, void* stream) {
+    MDP_REQUIRE(cfg && actions && actuated_idx && lower && upper && cur_targets && prev_targets && joint_pos_target && update,
+                "null pointer");
+    MDP_REQUIRE(ld_target >= cfg->num_dofs, "joint_pos_target row stride %d < %d dofs", ld_target, cfg->num_dofs);
+    SceneUpdatePlan plan;
+    int rc = scene_update_plan(update, &plan);
+    if (rc != MDP_OK) return rc;
+    MDP_REQUIRE(update->num_envs == cfg->num_envs, "scene update disagrees on num_envs");
+    int64_t total = (int64_t)cfg->num_envs * cfg->num_actuated;
+    if (total == 0) return MDP_OK;
+    const unsigned upd_total = plan.carried_total;
+    hipLaunchKernelGGL(k_apply_action_upd, dim3(upd_total + grid_for(total, 256)), dim3(256), 0, as_stream(stream), *cfg,
+                       actions, actuated_idx, lower, upper, cur_targets, prev_targets, joint_pos_target, ld_target,
+                       actions_copy == actions ? (float*)nullptr : actions_copy, plan.d, dt, upd_total, plan.nb_root,
+                       plan.nb_joint, plan.nb_contact, plan.carried_envs);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_inhand_dones_rewards_step(const mdp_inhand_cfg_t* cfg, float* object_root_state,
+                                             const float* env_origins, const float* in_hand_pos, const float* goal_rot,
+                                             float* successes, int64_t* episode_length_buf, uint8_t* reset_terminated,
+                                             uint8_t* reset_time_outs, uint8_t* reset_buf,
+                                             const float* object_transforms, const float* object_velocities,
+                                             const float* actions, uint8_t* reset_goal_buf, float* reward,
+                                             double* partials, const mdp_scene_update_t* update, float dt, void* stream) {
+    MDP_REQUIRE(cfg && object_root_state && env_origins && in_hand_pos && goal_rot && successes && episode_length_buf &&
+                    reset_terminated && reset_time_outs && reset_buf && actions && reset_goal_buf && reward && partials,
+                "null pointer");
+    MDP_REQUIRE((object_transforms == nullptr) == (object_velocities == nullptr),
+                "object_transforms and object_velocities go together");
+    if (cfg->num_envs == 0) return MDP_OK;
+    SceneUpdatePlan plan;
+    unsigned upd_total = 0;
+    if (update) {
+        int rc = scene_update_plan(update, &plan);
+        if (rc != MDP_OK) return rc;
+        MDP_REQUIRE(update->num_envs == cfg->num_envs, "scene update disagrees on num_envs");
+        upd_total = plan.carried_total;
+    } else {
+        plan.d = mdp_scene_update_t{};
+    }
+    hipLaunchKernelGGL(k_dones_rewards, dim3(upd_total + grid_for(cfg->num_envs, 256, 1 << 20)), dim3(256), 0,
+                       as_stream(stream), *cfg, object_root_state, env_origins, in_hand_pos, goal_rot, successes,
+                       episode_length_buf, reset_terminated, reset_time_outs, reset_buf, object_transforms,
+                       object_velocities, actions, reset_goal_buf, reward, partials, plan.d, dt, upd_total, plan.nb_root,
+                       plan.nb_joint, plan.nb_contact, plan.carried_envs);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -126,6 +126,8 @@ class InHandManipulationEnv:
     def fused_step(self, value: bool) -> None:
         # the step form expects clean partial sums on entry (it leaves them clean itself); the per-method form leaves
         # the last step's sums behind -- switching forms starts from zero
+        if getattr(self, "_pending_update", None) is not None:
+            self._flush_hand_update()
         self._fused_step = bool(value)
         self._partials.zero_()
         self._finish_pending = False
@@ -173,11 +175,15 @@ class InHandManipulationEnv:
             tgt = self.hand.joint_pos_target
             src = getattr(self, "_actions_in", None)
             self._actions_in = None
-            L.check(L.lib.mdp_inhand_apply_action_to(C.byref(self._ccfg), L.ptr(src if src is not None else self.actions),
-                                                     L.ptr(self.actions) if src is not None else None, L.ptr(self._act_idx),
-                                                     L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
-                                                     L.ptr(self.cur_targets), L.ptr(self.prev_targets), L.ptr(tgt),
-                                                     tgt.stride(0), L.stream()))
+            pend, self._pending_update = getattr(self, "_pending_update", None), None
+            args = (C.byref(self._ccfg), L.ptr(src if src is not None else self.actions),
+                    L.ptr(self.actions) if src is not None else None, L.ptr(self._act_idx),
+                    L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
+                    L.ptr(self.cur_targets), L.ptr(self.prev_targets), L.ptr(tgt), tgt.stride(0))
+            if pend is not None:     # the previous sub-step's hand.data.update(dt) rides in this launch
+                L.check(L.lib.mdp_inhand_apply_action_to_with_update(*args, C.byref(pend[0]), float(pend[1]), L.stream()))
+            else:
+                L.check(L.lib.mdp_inhand_apply_action_to(*args, L.stream()))
             return
         L.check(L.lib.mdp_inhand_apply_action(C.byref(self._ccfg), L.ptr(self.actions), L.ptr(self._act_idx),
                                               L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits),
@@ -206,21 +212,42 @@ class InHandManipulationEnv:
     def _dones_step(self) -> None:
         """direct_rl_env.py:343-346 as one launch: ``episode_length_buf += 1``, ``_get_dones`` written straight into
         ``reset_terminated`` / ``reset_time_outs``, ``reset_buf = reset_terminated | reset_time_outs``."""
-        od = self.object.data
-        xf = vel = None
-        if od._root_state_w.timestamp < od._sim_timestamp:
-            # the object's root_state_w is stale: this launch assembles it from the view (what the property's pack
-            # launch would do) and the rewards / observations behind it read the buffer it leaves
-            xf, vel = od._root_physx_view.get_transforms(), od._root_physx_view.get_root_velocities()
-            state = od._root_state_w.data
-            od._root_state_w.timestamp = od._sim_timestamp
-        else:
-            state = od.root_state_w
+        state, xf, vel = self._object_state_args()
         L.check(L.lib.mdp_inhand_dones_step(C.byref(self._ccfg), L.ptr(state),
                                             L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
                                             L.ptr(self.successes), L.ptr(self.episode_length_buf),
                                             L.ptr(self.reset_terminated), L.ptr(self.reset_time_outs),
                                             L.ptr(self.reset_buf), L.ptr(xf), L.ptr(vel), L.stream()))
+
+    def _object_state_args(self):
+        """(root_state buffer, view transforms, view velocities): with a stale ``root_state_w`` the launch assembles it
+        from the view (what the property's pack launch would do) and the launches behind it read the buffer it leaves."""
+        od = self.object.data
+        if od._root_state_w.timestamp < od._sim_timestamp:
+            od._root_state_w.timestamp = od._sim_timestamp
+            return od._root_state_w.data, od._root_physx_view.get_transforms(), od._root_physx_view.get_root_velocities()
+        return od.root_state_w, None, None
+
+    def _dones_rewards_step(self) -> None:
+        """direct_rl_env.py:343-349 as ONE launch (``mdp_inhand_dones_rewards_step``): ``_dones_step`` and the fused
+        ``_get_rewards`` per env in the same thread, with the last sub-step's deferred ``hand.data.update(dt)`` on blocks
+        of the same launch; the ``consecutive_successes`` average follows in the observation launch."""
+        state, xf, vel = self._object_state_args()
+        pend, self._pending_update = getattr(self, "_pending_update", None), None
+        L.check(L.lib.mdp_inhand_dones_rewards_step(
+            C.byref(self._ccfg), L.ptr(state), L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
+            L.ptr(self.successes), L.ptr(self.episode_length_buf), L.ptr(self.reset_terminated),
+            L.ptr(self.reset_time_outs), L.ptr(self.reset_buf), L.ptr(xf), L.ptr(vel), L.ptr(self.actions),
+            L.ptr(self.reset_goal_buf), L.ptr(self.reward_buf), L.ptr(self._partials),
+            C.byref(pend[0]) if pend is not None else None, float(pend[1]) if pend is not None else 0.0, L.stream()))
+        if self.group is not None:
+            import torch.distributed as dist
+
+            dist.all_reduce(self._partials, group=self.group)
+        self._finish_pending = True
+        if "log" not in self.extras:
+            self.extras["log"] = dict()
+        self.extras["log"]["consecutive_successes"] = self.consecutive_successes[0]
 
     def _get_rewards(self, defer_finish: bool = False) -> torch.Tensor:
         """:140-177 / compute_rewards :377-433.  ``defer_finish`` (only ``step()`` passes it): the moving average of
@@ -301,6 +328,22 @@ class InHandManipulationEnv:
         self.goal_rot[env_ids] = new_rot
         self.reset_goal_buf[env_ids] = False
 
+    def _defer_hand_update(self, dt: float) -> None:
+        """``self.hand.data.update(dt)`` described now (the view's buffers of THIS sub-step) and executed by the next
+        launch of the step (the next sub-step's ``_apply_action`` or ``_dones_rewards_step``): nothing in between reads
+        the hand's buffers."""
+        self._flush_hand_update()
+        d = L.MdpSceneUpdate()
+        self.hand.data.fill_scene_update(d, dt)
+        self.hand.data.commit_scene_update(dt)
+        self._pending_update = (d, dt)
+
+    def _flush_hand_update(self) -> None:
+        """Runs a deferred hand update on its own (a caller that reads the hand outside ``step()``)."""
+        pend, self._pending_update = getattr(self, "_pending_update", None), None
+        if pend is not None:
+            L.check(L.lib.mdp_scene_update(C.byref(pend[0]), float(pend[1]), L.stream()))
+
     def _update_hand_fused(self, dt: float) -> None:
         """``self.hand.data.update(dt)`` (articulation_data.py:77-82: timestamp, joint state refresh, joint_acc finite
         difference) as the one launch InteractiveScene.update uses (``mdp_scene_update``) instead of two copies and a
@@ -318,20 +361,21 @@ class InHandManipulationEnv:
             self._apply_action()
             self.hand_view.advance()                      # sim.step(): synthetic / replayed
             if self.fused_step:
-                self._update_hand_fused(self.physics_dt)
+                self._defer_hand_update(self.physics_dt)
             else:
                 self.hand.data.update(self.physics_dt)
             self.object.update(self.physics_dt)
         self.common_step_counter += 1
         if self.fused_step:
-            self._dones_step()
+            self._dones_rewards_step()
         else:
             self.episode_length_buf += 1
             terminated, time_outs = self._get_dones()
             self.reset_terminated[:] = terminated
             self.reset_time_outs[:] = time_outs
             torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
-        self.reward_buf = self._get_rewards(defer_finish=self.fused_step)
+        if not self.fused_step:
+            self.reward_buf = self._get_rewards()
         if reset_goals:                                    # :172-175 (host sync, like the reference)
             goal_env_ids = self.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)
             if len(goal_env_ids) > 0:
