@@ -61,12 +61,13 @@ __global__ void __launch_bounds__(256) k_apply_action_upd(mdp_inhand_cfg_t cfg, 
                                                           float* __restrict__ actions_copy, mdp_scene_update_t upd, float dt,
                                                           unsigned upd_total, unsigned nb_root, unsigned nb_joint,
                                                           unsigned nb_contact, int upd_envs) {
-    if (blockIdx.x < upd_total) {
-        scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
+    const unsigned task_blocks = gridDim.x - upd_total;
+    if (blockIdx.x >= task_blocks) {
+        scene_update_carried(upd, dt, blockIdx.x - task_blocks, nb_root, nb_joint, nb_contact, upd_envs);
         return;
     }
-    apply_action_blocks(cfg, actions, act_idx, lower, upper, cur, prev, target, ld_target, actions_copy,
-                        blockIdx.x - upd_total, gridDim.x - upd_total);
+    apply_action_blocks(cfg, actions, act_idx, lower, upper, cur, prev, target, ld_target, actions_copy, blockIdx.x,
+                        task_blocks);
 }
 
 // :179-199 for env e; returns the env's reset flag (direct_rl_env.py:346) and leaves the object's root state in row[13]
@@ -213,11 +214,14 @@ __global__ void __launch_bounds__(256) k_dones_rewards(mdp_inhand_cfg_t cfg, flo
                                                        double* __restrict__ partials, mdp_scene_update_t upd, float dt,
                                                        unsigned upd_total, unsigned nb_root, unsigned nb_joint,
                                                        unsigned nb_contact, int upd_envs) {
-    if (blockIdx.x < upd_total) {
-        scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
+    // the per-env blocks are the longer chain (loads -> dones -> rewards -> block sums -> atomics): they go first in the
+    // grid, the update blocks fill in behind them
+    const unsigned task_blocks = gridDim.x - upd_total;
+    if (blockIdx.x >= task_blocks) {
+        scene_update_carried(upd, dt, blockIdx.x - task_blocks, nb_root, nb_joint, nb_contact, upd_envs);
         return;
     }
-    int e = (blockIdx.x - upd_total) * blockDim.x + threadIdx.x;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
     double my_resets = 0.0, my_succ = 0.0;
     if (e < cfg.num_envs) {
         float row[13];
