@@ -948,6 +948,18 @@ typedef struct {                       /* push_by_setting_velocity, events.py:61
 } mdp_event_push_t;
 int mdp_event_push_by_setting_velocity(int num_envs, const mdp_event_push_t* args, void* stream);
 
+/* EventManager.apply(mode="reset") bookkeeping of the terms with min_step_count_between_reset == 0 (event_manager.py:
+ * 235-240: `last_triggered_step_id[env_ids] = global_env_step_count; last_triggered_once[env_ids] = True`) for the envs of
+ * env_mask (NULL = all), every such term in ONE launch instead of two index-put kernels per term. */
+#define MDP_EVENT_MARK_MAX_TERMS 8
+typedef struct {
+    int32_t num_terms;
+    int32_t step_count;
+    int32_t* last_triggered_step[MDP_EVENT_MARK_MAX_TERMS];   /* (N) int32 each */
+    uint8_t* triggered_once[MDP_EVENT_MARK_MAX_TERMS];        /* (N) bool each */
+} mdp_event_reset_mark_t;
+int mdp_event_reset_mark(int num_envs, const uint8_t* env_mask, const mdp_event_reset_mark_t* args, void* stream);
+
 /* EventManager.apply(mode="interval") for one term (event_manager.py:199-225): time_left -= dt; where it drops below
  * 1e-6 the timer is resampled (u * scale + lo) and trigger_mask = 1, else 0.  is_global_time: `time_left` is ONE
  * word shared by all envs (and injected_u / rng_state hold one uniform / one epoch). */
@@ -958,7 +970,9 @@ int mdp_event_interval_tick(int num_envs, float* time_left, float dt, float lo, 
  * update_env_origins (terrain_importer.py:307-324) for the envs of `env_mask`: the distance walked from the env origin
  * decides whether the env moves one terrain level up or down, envs beyond the last level get a random one, and the env
  * origin becomes terrain_origins[level, type].  terrain_levels / env_origins are updated in place; the term's return
- * value (mean level over ALL envs) is a plain reduction the caller does.  injected_levels: the randint draws (tests). */
+ * value (mean level over ALL envs, curriculums.py:55) is a plain reduction the caller does, or -- with mean_level and its
+ * two zero-initialised workspace words mean_ws -- written by the launch itself (integer block sums, last block writes
+ * sum * (1 / N) and clears the words).  injected_levels: the randint draws (tests). */
 typedef struct {
     const uint8_t* env_mask;
     const float* root_state_w;         /* (N, ld_state), columns 0..1 read */
@@ -975,6 +989,8 @@ typedef struct {
     float* env_origins;                /* (N,3) */
     const int64_t* injected_levels;    /* (N) or NULL */
     uint64_t* rng_state;               /* 1 + N words (see the event terms) */
+    float* mean_level;                 /* (1) or NULL */
+    unsigned long long* mean_ws;       /* 2 words, zero when first handed over; NULL iff mean_level is NULL */
 } mdp_curriculum_terrain_t;
 int mdp_curriculum_terrain_levels_vel(int num_envs, const mdp_curriculum_terrain_t* args, void* stream);
 

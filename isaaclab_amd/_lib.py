@@ -199,7 +199,15 @@ class MdpCurriculumTerrain(C.Structure):
                 ("max_terrain_level", C.c_int32), ("command", C.c_void_p), ("half_tile_size", C.c_float),
                 ("max_episode_length_s", C.c_float), ("terrain_levels", C.c_void_p), ("terrain_types", C.c_void_p),
                 ("terrain_origins", C.c_void_p), ("num_cols", C.c_int32), ("pad0", C.c_int32),
-                ("env_origins", C.c_void_p), ("injected_levels", C.c_void_p), ("rng_state", C.c_void_p)]
+                ("env_origins", C.c_void_p), ("injected_levels", C.c_void_p), ("rng_state", C.c_void_p),
+                ("mean_level", C.c_void_p), ("mean_ws", C.c_void_p)]
+
+
+class MdpEventResetMark(C.Structure):
+    """Mirror of ``mdp_event_reset_mark_t``."""
+
+    _fields_ = [("num_terms", C.c_int32), ("step_count", C.c_int32), ("last_triggered_step", C.c_void_p * 8),
+                ("triggered_once", C.c_void_p * 8)]
 
 
 class MdpImuArgs(C.Structure):

@@ -159,9 +159,7 @@ __global__ void k_interval_tick_global(int N, float* time_left, float dt, float 
 }
 
 // curriculums.py:26-55 (terrain_levels_vel) + terrain_importer.py:307-324 (update_env_origins)
-__global__ void k_terrain_levels_vel(int N, mdp_curriculum_terrain_t a) {
-    int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= N || (a.env_mask && !a.env_mask[e])) return;
+__device__ __forceinline__ int64_t terrain_levels_vel_env(int e, const mdp_curriculum_terrain_t& a) {
     const float* r = a.root_state_w + (int64_t)e * a.ld_state;
     float* org = a.env_origins + 3 * (int64_t)e;
     float distance = norm2(r[0] - org[0], r[1] - org[1]);
@@ -184,6 +182,48 @@ __global__ void k_terrain_levels_vel(int N, mdp_curriculum_terrain_t a) {
     a.terrain_levels[e] = level;
     const float* o = a.terrain_origins + ((int64_t)level * a.num_cols + a.terrain_types[e]) * 3;
     org[0] = o[0]; org[1] = o[1]; org[2] = o[2];
+    return level;
+}
+
+// With mean_level set the launch also returns what the term returns, torch.mean(terrain_levels.float()) over ALL envs
+// (curriculums.py:55): every thread contributes its env's level (updated or not), blocks add up integers -- exact in any
+// order -- and the last block to finish (a ticket) writes sum * (1 / N), torch's own expression, and clears the words.
+__global__ void k_terrain_levels_vel(int N, mdp_curriculum_terrain_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    long long level = 0;
+    if (e < N) {
+        if (a.env_mask && !a.env_mask[e]) level = a.mean_level ? (long long)a.terrain_levels[e] : 0;
+        else level = (long long)terrain_levels_vel_env(e, a);
+    }
+    if (!a.mean_level) return;
+    __shared__ long long s_sum[16];
+    for (int off = 32; off > 0; off >>= 1) level += __shfl_down(level, off);
+    if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = level;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long block = 0;
+        for (int w = 0; w < (int)((blockDim.x + 63) >> 6); ++w) block += s_sum[w];
+        unsigned long long* ws = a.mean_ws;
+        // the ticket's increment is computed from the value the first atomic returned (its top bit is never set): the
+        // sum is in place before the ticket is taken, without a fence
+        const unsigned long long before = atomicAdd(&ws[0], (unsigned long long)block);
+        const unsigned long long ticket = atomicAdd(&ws[1], 1ull + (before >> 63));
+        if (ticket == (unsigned long long)gridDim.x - 1) {
+            const long long total = (long long)atomicExch(&ws[0], 0ull);
+            atomicExch(&ws[1], 0ull);
+            a.mean_level[0] = (float)total * (1.0f / (float)N);
+        }
+    }
+}
+
+// event_manager.py:235-240 for every reset term with min_step_count_between_reset == 0, one thread per env
+__global__ void k_event_reset_mark(int N, const uint8_t* __restrict__ mask, mdp_event_reset_mark_t a) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N || (mask && !mask[e])) return;
+    for (int t = 0; t < a.num_terms; ++t) {
+        a.last_triggered_step[t][e] = a.step_count;
+        a.triggered_once[t][e] = 1;
+    }
 }
 
 // Imu._update_buffers_impl (LAB/sensors/imu/imu.py:142-182) for the outdated envs; one thread per env
@@ -309,8 +349,22 @@ extern "C" int mdp_curriculum_terrain_levels_vel(int num_envs, const mdp_curricu
                     a->env_origins, "null pointer");
     MDP_REQUIRE(a->ld_state >= 3 && a->max_terrain_level >= 1 && a->num_cols >= 1, "bad shape");
     MDP_REQUIRE(a->injected_levels || a->rng_state, "need rng_state or injected_levels");
+    MDP_REQUIRE((a->mean_level == nullptr) == (a->mean_ws == nullptr), "mean_level and mean_ws go together");
     if (num_envs <= 0) return MDP_OK;
     hipLaunchKernelGGL(k_terrain_levels_vel, dim3(grid_for(num_envs, 128)), dim3(128), 0, as_stream(stream), num_envs, *a);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_event_reset_mark(int num_envs, const uint8_t* env_mask, const mdp_event_reset_mark_t* a, void* stream) {
+    MDP_REQUIRE(a, "null arguments");
+    MDP_REQUIRE(a->num_terms >= 0 && a->num_terms <= MDP_EVENT_MARK_MAX_TERMS, "at most %d terms per launch (got %d)",
+                MDP_EVENT_MARK_MAX_TERMS, a->num_terms);
+    for (int t = 0; t < a->num_terms; ++t)
+        MDP_REQUIRE(a->last_triggered_step[t] && a->triggered_once[t], "term %d: null buffer", t);
+    if (num_envs <= 0 || a->num_terms == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_event_reset_mark, dim3(grid_for(num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), num_envs,
+                       env_mask, *a);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -10,6 +10,8 @@ from __future__ import annotations
 
 from collections.abc import Sequence
 
+import ctypes as C
+
 import torch
 
 from .. import _lib as L
@@ -75,6 +77,20 @@ class EventManager(ManagerBase):
         if mode == "reset" and global_env_step_count is None:
             raise ValueError(f"Event mode '{mode}' requires the total number of environment steps to be provided.")
 
+        marked = False
+        if mode == "reset" and isinstance(env_ids, torch.Tensor) and env_ids.dtype in (torch.uint8, torch.bool) \
+                and env_ids.is_cuda and env_ids.is_contiguous():
+            # the sync-free reset path (a device mask): the bookkeeping of every term without a minimum step count
+            # (event_manager.py:235-240) in ONE launch instead of two index-put kernels per term
+            idx = [i for i, c in enumerate(self._mode_term_cfgs[mode]) if c.min_step_count_between_reset == 0]
+            if 0 < len(idx) <= 8:
+                a = L.MdpEventResetMark()
+                a.num_terms, a.step_count = len(idx), int(global_env_step_count)
+                for k, i in enumerate(idx):
+                    a.last_triggered_step[k] = self._reset_term_last_triggered_step_id[i].data_ptr()
+                    a.triggered_once[k] = self._reset_term_last_triggered_once[i].data_ptr()
+                L.check(L.lib.mdp_event_reset_mark(self.num_envs, env_ids.data_ptr(), C.byref(a), L.stream(self.device)))
+                marked = True
         for index, term_cfg in enumerate(self._mode_term_cfgs[mode]):
             if mode == "interval":
                 lower, upper = term_cfg.interval_range_s
@@ -90,9 +106,10 @@ class EventManager(ManagerBase):
             elif mode == "reset":
                 min_step_count = term_cfg.min_step_count_between_reset
                 if min_step_count == 0:
-                    sel = slice(None) if env_ids is None else self._as_index(env_ids)
-                    self._reset_term_last_triggered_step_id[index][sel] = global_env_step_count
-                    self._reset_term_last_triggered_once[index][sel] = True
+                    if not marked:
+                        sel = slice(None) if env_ids is None else self._as_index(env_ids)
+                        self._reset_term_last_triggered_step_id[index][sel] = global_env_step_count
+                        self._reset_term_last_triggered_once[index][sel] = True
                     term_cfg.func(self._env, env_ids, **term_cfg.params)
                 else:
                     # event_manager.py:242-268 with masks instead of id lists

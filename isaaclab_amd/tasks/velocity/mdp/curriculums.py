@@ -36,5 +36,22 @@ def terrain_levels_vel(env, env_ids: Sequence[int], asset_cfg: SceneEntityCfg = 
     inj = getattr(env, "event_uniforms", {}).get("terrain_levels_vel")       # tests: the randint draws, (N,) int64
     a.injected_levels = inj.data_ptr() if inj is not None else None
     a.rng_state = None if inj is not None else _state(env, ("terrain_levels", asset_cfg.name), 7).data_ptr()
+    # the term's return value, torch.mean(terrain_levels.float()) (:55), written by the launch itself: a fresh
+    # one-element tensor per call like the reference's, or a slot of a ring (env.reset_log_ring, no copy launch)
+    ws = st.get("mean_ws")
+    if ws is None:
+        ws = st["mean_ws"] = torch.zeros(2, dtype=torch.int64, device=env.device)
+        st["mean_out"] = torch.zeros(1, dtype=torch.float32, device=env.device)
+    ring = int(getattr(env, "reset_log_ring", 0) or 0)
+    if ring > 0:
+        slots = st.get("mean_ring")
+        if slots is None or slots.shape[0] != ring:
+            slots = st["mean_ring"] = torch.zeros(ring, dtype=torch.float32, device=env.device)
+            st["mean_slot"] = 0
+        out = slots[st["mean_slot"]: st["mean_slot"] + 1]
+        st["mean_slot"] = (st["mean_slot"] + 1) % ring
+    else:
+        out = st["mean_out"]
+    a.mean_level, a.mean_ws = out.data_ptr(), ws.data_ptr()
     L.check(L.lib.mdp_curriculum_terrain_levels_vel(env.num_envs, C.byref(a), L.stream(env.device)))
-    return torch.mean(st["terrain_levels"].float())
+    return out[0] if ring > 0 else out[0].clone()
