@@ -191,3 +191,74 @@ def test_gpu_inhand_step_full_size_vs_oracle(device, fused):
     assert_close(to_np(env.hand.data.joint_pos), q)
     assert_close(to_np(env.hand.data.joint_vel), qd)
     assert np.abs(to_np(env.hand.data.joint_acc)).max() == 0.0      # the frame is held: no velocity change
+
+
+@pytest.mark.gpu
+def test_gpu_inhand_fused_step_equals_per_statement_step_over_changing_frames(device):
+    """Three steps with a NEW physics frame every sub-step (written in place into the view's buffers, the harshest case
+    for the launches that carry the previous sub-step's hand update): the four-launch step and the one-launch-per-
+    statement step leave every buffer bit-identical -- joint state incl. the joint_acc finite difference, targets, dones,
+    episode counters, rewards, successes, their moving average, observations."""
+    import torch
+
+    n, D, B, A, steps = 1000, 24, 26, 20, 3
+    rng = np.random.RandomState(5)
+    f = lambda *s: rng.randn(*s).astype(np.float32)
+    origins = f(n, 3) * 3
+    lower = -1.0 - rng.rand(n, D).astype(np.float32)
+    upper = 1.0 + rng.rand(n, D).astype(np.float32)
+    goal = f(n, 4); goal /= np.linalg.norm(goal, axis=1, keepdims=True)
+    frames = []
+    for _ in range(steps * 2):
+        quat = f(n, 4); quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+        quat[::7] = goal[::7]
+        obj = np.concatenate([f(n, 3) * 0.12 + np.array([0.0, -0.39, 0.6], np.float32) + origins, quat, f(n, 6)], 1)
+        frames.append((obj.astype(np.float32), f(n, B, 13), (lower + (upper - lower) * rng.rand(n, D)).astype(np.float32), f(n, D)))
+    actions = [(rng.rand(n, A) * 2 - 1).astype(np.float32) for _ in range(steps)]
+    prev = f(n, D) * 0.5
+    succ0 = rng.randint(0, 5, n).astype(np.float32)
+    ep0 = rng.randint(0, 400, n)
+    results = []
+    for fused in (True, False):
+        env = _make_env(n, device, origins, lower, upper, act_moving_average=0.7)
+        env.fused_step = fused
+        ep0[::50] = env.max_episode_length - 2
+        env.goal_rot.copy_(to_dev(goal, device))
+        env.prev_targets.copy_(to_dev(prev, device))
+        env.successes.copy_(to_dev(succ0, device))
+        env.episode_length_buf.copy_(to_dev(ep0, device))
+        env.consecutive_successes.fill_(1.3)
+        _feed(env, device, *frames[0])
+        cursor = [0]
+
+        def advance(env=env, cursor=cursor):
+            obj, body, q, qd = frames[cursor[0] % len(frames)]
+            cursor[0] += 1
+            xyzw = np.concatenate([obj[:, :3], obj[:, 4:7], obj[:, 3:4]], axis=1)
+            env.object_view.transforms.copy_(to_dev(xyzw, device))
+            env.object_view.velocities.copy_(to_dev(obj[:, 7:], device))
+            lt = np.concatenate([body[..., :3], body[..., 4:7], body[..., 3:4]], axis=-1)
+            env.hand_view.get_link_transforms().copy_(to_dev(lt, device))
+            env.hand_view.get_link_velocities().copy_(to_dev(body[..., 7:], device))
+            env.hand_view.get_dof_positions().copy_(to_dev(q, device))
+            env.hand_view.get_dof_velocities().copy_(to_dev(qd, device))
+
+        env.hand_view.advance = advance
+        out = []
+        for t in range(steps):
+            obs, rew, term, tout, extras = env.step(to_dev(actions[t], device))
+            torch.cuda.synchronize()
+            out.append([to_np(x).copy() for x in (
+                obs["policy"], rew, term, tout, env.reset_buf, env.episode_length_buf, env.successes,
+                env.consecutive_successes, env.reset_goal_buf, env.cur_targets, env.prev_targets, env.hand.joint_pos_target,
+                env.actions, env.hand.data.joint_pos, env.hand.data.joint_vel, env.hand.data.joint_acc,
+                env.object.data.root_state_w)] + [np.float32(float(extras["log"]["consecutive_successes"]))])
+        results.append(out)
+    names = ("obs", "reward", "terminated", "time_outs", "reset_buf", "episode_length", "successes", "consecutive_successes",
+             "reset_goal_buf", "cur_targets", "prev_targets", "joint_pos_target", "actions", "joint_pos", "joint_vel",
+             "joint_acc", "object_root_state", "logged")
+    for t in range(steps):
+        for name, a, b in zip(names, results[0][t], results[1][t]):
+            np.testing.assert_array_equal(a, b, err_msg=f"{name}, step {t}")
+    assert np.abs(results[0][-1][15]).max() > 0.0            # joint_acc: the velocities did change between sub-steps
+    assert results[0][-1][2].sum() > 0 and results[0][-1][8].sum() > 0
