@@ -141,6 +141,10 @@ int mdp_joint_acc_update(int num_envs, int num_joints, const float* joint_vel, i
 /* root_state_w / body_state_w assembly (articulation_data.py:264-279,329-346): pose (count,7) in the
  * physics engine's xyzw convention + velocity (count,6) -> state (count,13) with wxyz quaternions. */
 int mdp_state_pack(int64_t count, const float* pose_xyzw, const float* velocity, float* state_out, void* stream);
+/* The same for the rows of `num_ids` bodies (device ids) of every env of a (N, num_bodies, .) layout: a term that reads two
+ * of twenty bodies (feet_slide) does not need the other eighteen assembled; the other rows are left untouched. */
+int mdp_state_pack_rows(int64_t num_envs, int num_bodies, const int32_t* body_ids, int num_ids, const float* pose_xyzw,
+                        const float* velocity, float* state_out, void* stream);
 
 /* Derived root quantities (articulation_data.py:412-425,503-518): any output may be NULL.
  * root_state is (N,13) [pos, quat wxyz, lin_vel, ang_vel]; gravity_dir is the unit gravity vector. */

@@ -127,6 +127,17 @@ class ArticulationData:
             self._body_state_w.timestamp = self._sim_timestamp
         return self._body_state_w.data
 
+    def body_state_rows(self, body_ids: torch.Tensor):
+        """``body_state_w`` with only the rows of ``body_ids`` (device int32) brought up to date when the buffer is stale
+        (``mdp_state_pack_rows``): for kernels that read a few bodies.  The buffer's timestamp is left alone, so any
+        other reader still gets the full assembly."""
+        if self._body_state_w.timestamp < self._sim_timestamp:
+            v = self._root_physx_view
+            L.check(L.lib.mdp_state_pack_rows(self._num_instances, self._num_bodies, L.ptr(body_ids), int(body_ids.numel()),
+                                              L.ptr(v.get_link_transforms()), L.ptr(v.get_link_velocities()),
+                                              L.ptr(self._body_state_w.data), L.stream()))
+        return self._body_state_w.data
+
     @property
     def body_link_state_w(self):
         if self._body_link_state_w.timestamp < self._sim_timestamp:

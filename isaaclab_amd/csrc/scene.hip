@@ -43,6 +43,24 @@ __global__ void k_state_pack(int64_t count, const float* __restrict__ pose, cons
     }
 }
 
+// the same for `num_ids` of the B bodies of every env only (rows of the other bodies are left as they are)
+__global__ void k_state_pack_rows(int64_t num_envs, int B, const int32_t* __restrict__ ids, int num_ids,
+                                  const float* __restrict__ pose, const float* __restrict__ vel, float* __restrict__ out) {
+    const int64_t total = num_envs * num_ids * 13;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / 13;
+        const int k = (int)(i - row * 13);
+        const int64_t e = row / num_ids;
+        const int64_t r = e * B + ids[(int)(row - e * num_ids)];
+        float v;
+        if (k < 3) v = pose[7 * r + k];
+        else if (k == 3) v = pose[7 * r + 6];       // w
+        else if (k < 7) v = pose[7 * r + k - 1];    // x, y, z
+        else v = vel[6 * r + (k - 7)];
+        out[13 * r + k] = v;
+    }
+}
+
 // articulation_data.py:412-425,503-518
 __global__ void k_root_derive(int N, const float* __restrict__ st, int ld, float gx, float gy, float gz,
                               float* __restrict__ lin_b, float* __restrict__ ang_b, float* __restrict__ grav_b,
@@ -252,6 +270,17 @@ extern "C" int mdp_state_pack(int64_t count, const float* pose_xyzw, const float
     if (count == 0) return MDP_OK;
     hipLaunchKernelGGL(k_state_pack, dim3(grid_for(count * 13, 256)), dim3(256), 0, as_stream(stream), count,
                        pose_xyzw, velocity, state_out);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_state_pack_rows(int64_t num_envs, int num_bodies, const int32_t* body_ids, int num_ids,
+                                   const float* pose_xyzw, const float* velocity, float* state_out, void* stream) {
+    MDP_REQUIRE(body_ids && pose_xyzw && velocity && state_out, "null pointer");
+    MDP_REQUIRE(num_bodies > 0 && num_ids >= 0 && num_ids <= num_bodies, "bad body counts (%d of %d)", num_ids, num_bodies);
+    if (num_envs <= 0 || num_ids == 0) return MDP_OK;
+    hipLaunchKernelGGL(k_state_pack_rows, dim3(grid_for(num_envs * num_ids * 13, 256)), dim3(256), 0, as_stream(stream),
+                       num_envs, num_bodies, body_ids, num_ids, pose_xyzw, velocity, state_out);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

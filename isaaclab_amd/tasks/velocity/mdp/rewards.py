@@ -1,6 +1,8 @@
 """Task rewards (``TASKS/manager_based/locomotion/velocity/mdp/rewards.py:25-106``)."""
 from __future__ import annotations
 
+import torch
+
 from ...._terms import REWARD, TermSpec, ids_to_list, lowered
 from ....envs.mdp._common import contact_history, f32, mat, root_state
 from ....managers.scene_entity_cfg import SceneEntityCfg
@@ -43,8 +45,14 @@ def feet_slide(env, sensor_cfg: SceneEntityCfg, asset_cfg: SceneEntityCfg = Scen
     n2 = asset.num_bodies if idx2 is None else len(idx2)
     if n1 != n2:
         raise RuntimeError(f"The size of tensor a ({n2}) must match the size of tensor b ({n1}) at non-singleton dimension 1")
+    if idx2 is None or not hasattr(asset.data, "body_state_rows"):
+        refresh = lambda d=asset.data: d.body_state_w
+    else:
+        # only the rows the term reads (H1: 2 of 20 bodies) instead of the whole (N, B, 13) assembly every step
+        rows = torch.tensor(idx2, dtype=torch.int32, device=body.device)
+        refresh = lambda d=asset.data, rows=rows: d.body_state_rows(rows)
     return TermSpec(REWARD, "MDP_REW_FEET_SLIDE", p={0: hist, 1: body}, i={0: h, 1: bs, 2: asset.num_bodies},
-                    idx=idx, idx2=idx2, before=before + [lambda d=asset.data: d.body_state_w])
+                    idx=idx, idx2=idx2, before=before + [refresh])
 
 
 def _track(op, env, std, command_name, asset_cfg):
