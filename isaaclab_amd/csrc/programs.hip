@@ -1502,12 +1502,14 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
     // the step the manager chain outlasts the cast: 74.6 us/step with 24, 73.3 with 16, 73.5 with 12, 74.9 with 8), a full wave of lanes per term once the cast runs for several rounds (fewer manager blocks
     // holding wave slots the cast could use; whole-step bench: 204.2 -> 202.0 us at 16384 envs with 32, 743 -> 729 us at
     // 65536 envs with 64; at 8192 envs 24 is still best)
-    // without a cast there is nobody to take wave slots from: 8-env blocks (flat Anymal-D, 4096 envs: 51.1 us/step with
-    // 24, 49.3 with 16, 48.3 with 8)
+    // Without a cast there is nobody to take wave slots from, and a manager block's phases are loops of one term per
+    // wave and round trip (17 reward terms on 4 waves: five round trips one after the other): blocks of 12 waves with
+    // 16 envs each (flat Anymal-D, 4096 envs, us/step: 256 threads x 8 envs 49.0, x 16 49.3, x 24 51.1; 384 x 8 46.7;
+    // 768 x 12 47.2, x 16 45.6 - 45.8, x 24 46.5, x 32 46.0; post-physics launch 22.1 -> 17.8 us)
     const int post_envs = post_envs_forced > 0 ? post_envs_forced
-                          : (!cast && num_envs < 12288) ? 8
+                          : (!cast && num_envs < 12288) ? 16
                           : (num_envs >= 32768 ? 64 : (num_envs >= 12288 ? 32 : (num_envs >= 6144 ? 24 : 16)));
-    int threads = threads_env > 0 ? threads_env : 256;
+    int threads = threads_env > 0 ? threads_env : (cast ? 256 : MDP_POST_MAX_THREADS);
     if (threads_env <= 0 && cast && cast->num_rays > 0 && cast->num_rays < 256)
         threads = (((256 / cast->num_rays) * cast->num_rays + 63) / 64) * 64;   // 187 rays -> 192 threads
     // ---- cast
