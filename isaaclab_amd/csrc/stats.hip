@@ -50,8 +50,24 @@ __global__ void k_masked_sums(const float* __restrict__ v, int rows, int N, cons
     __shared__ double rs[256];
     __shared__ double rc[256];
     double s = 0.0, c = 0.0;
-    for (int e = threadIdx.x; e < N; e += blockDim.x) {
-        if (!mask || mask[e]) { s += (double)v[(int64_t)k * N + e]; c += 1.0; }
+    // eight elements per trip, their loads issued before the first add (with a branch per element every load is its own
+    // round trip, N / 256 of them per thread); a masked-out element adds an exact zero: same order, same sums
+    const float* row = v + (int64_t)k * N;
+    for (int e0 = threadIdx.x; e0 < N; e0 += 8 * blockDim.x) {
+        float x[8];
+        uint8_t m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + j * blockDim.x;
+            const bool in = e < N;
+            x[j] = in ? row[e] : 0.0f;
+            m[j] = in ? (mask ? mask[e] : (uint8_t)1) : (uint8_t)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s += m[j] ? (double)x[j] : 0.0;
+            c += m[j] ? 1.0 : 0.0;
+        }
     }
     rs[threadIdx.x] = s;
     rc[threadIdx.x] = c;
