@@ -177,6 +177,10 @@ def main():
         if args.auto_reset != "off" or args.events or args.normalize_obs:
             raise SystemExit("--auto-reset / --events / --normalize-obs belong to the velocity configs")
         env, rec, actions = make_shadow_env(args, device, ring, seed=1234 + 1 + 1000 * rank)
+        if world > 1:       # consecutive_successes (:424-431) is reduced over every rank's envs inside the step
+            import torch.distributed as dist
+
+            env.group = dist.group.WORLD
         stats = None
     else:
         env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
@@ -320,7 +324,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_shadow(rec, args) if shadow else cpu_baseline(rec, args)
         out = {
-            "metric": "env-steps/sec of MDP compute (Anymal-C rough, 4096 envs/GPU) + % HBM peak",
+            # BASELINE.json's metric text for the configuration it is quoted on; any other --config / --envs says what it ran
+            "metric": ("env-steps/sec of MDP compute (Anymal-C rough, 4096 envs/GPU) + % HBM peak"
+                       if args.config == "anymal_c_rough" and args.envs == 4096 else
+                       f"env-steps/sec of MDP compute ({args.config}, {args.envs} envs/GPU) + % HBM peak"),
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -330,8 +337,11 @@ def main():
                        "timed_regions": int(len(times)), "region_ms_median": 1e3 * elapsed,
                        "region_ms_p10": 1e3 * float(np.percentile(times, 10)),
                        "region_ms_p90": 1e3 * float(np.percentile(times, 90)), "first_region_ms": 1e3 * first,
-                       "stats_allreduce_every": args.stats_every, "auto_reset": args.auto_reset, "events": bool(args.events), "normalize_obs": bool(args.normalize_obs),
-                       "reset_envs_last_step": resets,
+                       "stats_allreduce_every": args.stats_every,
+                       "auto_reset": env.auto_reset if shadow else args.auto_reset,
+                       **({"reset_goals": bool(env.reset_goals)} if shadow else {}),
+                       "events": bool(args.events), "normalize_obs": bool(args.normalize_obs),
+                       "reset_envs_last_step": float(env.reset_buf.sum().item()) if shadow else resets,
                        "reset_log_ring": int(getattr(env, "reset_log_ring", 0) or 0)},
             "roofline": roof, "cpu_baseline": cpu,
         }
@@ -420,7 +430,9 @@ def measure_roofline_shadow(env, actions) -> dict:
         "dones": (env._get_dones, 4 * (7 + 3 + 4 + 1) + 8 + 2, "k_inhand_dones"),
         "rewards": (env._get_rewards, 4 * (7 + 3 + 4 + A + 1) + 2 + 4 + 1, "k_inhand_rewards"),
         "observations": (env.compute_full_observations, 4 * (2 * J + 13 + 13 * Fg + A) + 4 * env.num_full_obs,
-                         "k_inhand_full_obs"),
+                         "k_inhand_obs"),
+        # masked _reset_idx of the step's done envs: one flag per env in, the reset rows of the few flagged envs out
+        "reset_idx": (lambda: env._reset_idx_masked(env.reset_buf), 1, "k_inhand_reset_idx"),
     }
     per_kernel = {}
     for name, (fn, nbytes, frag) in stages.items():

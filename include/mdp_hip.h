@@ -562,6 +562,22 @@ typedef struct {
     int64_t max_episode_length;
 } mdp_inhand_cfg_t;
 
+/* _reset_target_pose (:248-260) for the envs of a byte mask instead of the id list the reference takes from nonzero()
+ * (:173): new goal_rot = randomize_rotation(u0, u1, x_unit, y_unit) (:363-367) with u = 2 * rand - 1 (sample_uniform,
+ * math.py:1331), reset_goal_buf cleared.  Draws: `injected_u` (N, ld_injected) -- columns [0, 2) -- or the device
+ * generator rng_state = {seed, one epoch word per env} (an env's word advances when it draws: hipGraph replays keep
+ * drawing).  The goal markers (:257-258) are visualisation and out of scope. */
+typedef struct {
+    const uint8_t* env_mask;      /* (N) or NULL = every env; ignored by mdp_inhand_dones_rewards_step (own goal_resets) */
+    const float* injected_u;      /* or NULL */
+    int32_t ld_injected, pad0;
+    uint64_t* rng_state;          /* 1 + N words; required when injected_u is NULL */
+    const float* x_unit;          /* (N,3) */
+    const float* y_unit;          /* (N,3) */
+    float* goal_rot;              /* (N,4) wxyz */
+    uint8_t* reset_goal_buf;      /* (N) */
+} mdp_inhand_goal_reset_t;
+
 /* _apply_action (inhand_manipulation_env.py:97-117): scale -> moving average -> saturate, in place
  * on cur_targets / prev_targets (N, num_dofs) for the actuated columns (device int32 indices). */
 int mdp_inhand_apply_action(const mdp_inhand_cfg_t* cfg, const float* actions, const int32_t* actuated_idx,
@@ -632,7 +648,10 @@ int mdp_inhand_dones_rewards_step(const mdp_inhand_cfg_t* cfg, float* object_roo
                                   uint8_t* reset_buf, const float* object_transforms /* (N,7) xyzw or NULL */,
                                   const float* object_velocities /* (N,6) or NULL */, const float* actions,
                                   uint8_t* reset_goal_buf, float* reward, double* partials,
-                                  const mdp_scene_update_t* update /* or NULL */, float dt, void* stream);
+                                  const mdp_scene_update_t* update /* or NULL */, float dt,
+                                  const mdp_inhand_goal_reset_t* goal_reset /* or NULL: the goal reset of _get_rewards
+                                  (:172-175) for the envs whose goal_resets this launch sets */,
+                                  void* stream);
 int mdp_inhand_dones_step(const mdp_inhand_cfg_t* cfg, float* object_root_state, const float* env_origins,
                           const float* in_hand_pos, const float* goal_rot, const float* successes,
                           int64_t* episode_length_buf, uint8_t* reset_terminated, uint8_t* reset_time_outs,
@@ -652,6 +671,71 @@ int mdp_inhand_full_obs_from_view(const mdp_inhand_cfg_t* cfg, const float* join
                                   const float* actions, int action_dim, float* obs, int ld_obs,
                                   double* partials /* or NULL */, float* consecutive_successes /* or NULL */,
                                   void* stream);
+
+/* _reset_target_pose (:248-260) as a masked launch: mdp_inhand_goal_reset_t above. */
+int mdp_inhand_reset_target_pose(const mdp_inhand_cfg_t* cfg, const mdp_inhand_goal_reset_t* goal, void* stream);
+
+/* InHandManipulationEnv._reset_idx (:201-246) + DirectRLEnv._reset_idx (direct_rl_env.py:560-581) for the envs of a byte
+ * mask, one launch, nothing synchronises with the host: goal (as above), object root state = default + position noise +
+ * env origin, randomize_rotation of two more draws, zero velocity, written like RigidObject.write_root_pose_to_sim /
+ * write_root_velocity_to_sim (rigid_object.py:192-213, 268-290: data buffer and the physics view's xyzw transforms /
+ * velocities); hand joint state = default + noise scaled into the joint range (:228-236), written like
+ * Articulation.write_joint_state_to_sim (articulation.py:472-508: joint_pos, joint_vel, previous velocity, joint_acc = 0
+ * and the view's dof buffers) and into prev_targets / cur_targets / hand_dof_targets / joint_pos_target (:238-242);
+ * successes = 0, episode_length_buf = 0.  Draw order per env as the reference's torch.rand calls: goal 2, position 3,
+ * rotation 2, dof positions D, dof velocities D (injected_u columns in that order, ld_injected >= 7 + 2 D). */
+typedef struct {
+    mdp_inhand_goal_reset_t goal;                 /* env_mask, draws, goal buffers */
+    float reset_position_noise, reset_dof_pos_noise, reset_dof_vel_noise, pad0;
+    const float* object_default_root_state;       /* (N,13) */
+    const float* env_origins;                     /* (N,3) */
+    float* object_root_state_w;                   /* (N,13) */
+    float* sim_object_transforms;                 /* (N,7) xyzw */
+    float* sim_object_velocities;                 /* (N,6) */
+    const float* default_joint_pos; const float* default_joint_vel; const float* lower; const float* upper; /* (N,D) */
+    float* prev_targets; float* cur_targets; float* hand_dof_targets;   /* (N,D) */
+    float* joint_pos_target; int32_t ld_target, ld_sim;
+    float* joint_pos; float* joint_vel; float* prev_joint_vel; float* joint_acc;   /* (N,D) */
+    float* sim_dof_positions; float* sim_dof_velocities;                          /* (N, ld_sim) */
+    float* successes;                             /* (N) */
+    int64_t* episode_length_buf;                  /* (N) */
+} mdp_inhand_reset_t;
+int mdp_inhand_reset_idx(const mdp_inhand_cfg_t* cfg, const mdp_inhand_reset_t* args, void* stream);
+
+/* The three observation layouts of the env in ONE launch (:119-138): `policy` = compute_full_observations (:298-322, 157
+ * columns for the Shadow hand) or compute_reduced_observations (:281-296: fingertip positions, object position,
+ * quat_mul(object_rot, conj(goal_rot)), actions = 42), and -- asymmetric_obs -- `critic` = compute_full_state (:324-350:
+ * the full layout with force_torque_obs_scale * fingertip force sensors in front of the actions, 187).  Fingertip rows
+ * come from body_state_w (N,B,13) or, when that is NULL, from the physics view's link buffers as in
+ * mdp_inhand_full_obs_from_view; link_incoming_joint_force (N,B,6) is the view's get_link_incoming_joint_force()
+ * (:121-123), read for the critic only.  A kind < 0 skips that output.  partials / consecutive_successes as for
+ * mdp_inhand_full_obs_from_view. */
+enum { MDP_INHAND_OBS_FULL = 0, MDP_INHAND_OBS_REDUCED = 1, MDP_INHAND_OBS_FULL_STATE = 2 };
+typedef struct {
+    const float* joint_pos; const float* joint_vel; const float* lower; const float* upper;
+    const float* object_root_state; const float* env_origins; const float* in_hand_pos; const float* goal_rot;
+    const float* body_state_w;              /* (N,B,13) or NULL */
+    const float* link_transforms;           /* (N,B,7) xyzw, used when body_state_w is NULL */
+    const float* link_velocities;           /* (N,B,6) */
+    const float* link_incoming_joint_force; /* (N,B,6); required for MDP_INHAND_OBS_FULL_STATE */
+    const int32_t* finger_bodies;
+    const float* actions;
+    int32_t action_dim;
+    float force_torque_obs_scale;
+    int32_t policy_kind, ld_policy;
+    float* policy;
+    int32_t critic_kind, ld_critic;
+    float* critic;
+    double* partials;                       /* or NULL */
+    float* consecutive_successes;           /* or NULL */
+    const mdp_inhand_reset_t* reset;        /* or NULL: mdp_inhand_reset_idx of the envs of reset->goal.env_mask by the block
+                                               that owns them, in front of their observations (direct_rl_env.py:355-372:
+                                               every buffer both touch is the env's own row) -- no launch of its own */
+} mdp_inhand_obs_args_t;
+int mdp_inhand_observations(const mdp_inhand_cfg_t* cfg, const mdp_inhand_obs_args_t* args, void* stream);
+/* number of columns of a layout for this cfg (0 for an unknown kind) */
+int mdp_inhand_obs_dim(const mdp_inhand_cfg_t* cfg, int kind, int action_dim);
+
 
 /* ------------------------------------------------------------------------------------------
  * Statistics for the cross-GPU reductions: per-rank partials in fp64.

@@ -262,6 +262,44 @@ class MdpInhandCfg(C.Structure):
     ]
 
 
+class MdpInhandGoalReset(C.Structure):
+    """Mirror of ``mdp_inhand_goal_reset_t``."""
+
+    _fields_ = [("env_mask", C.c_void_p), ("injected_u", C.c_void_p), ("ld_injected", C.c_int32), ("pad0", C.c_int32),
+                ("rng_state", C.c_void_p), ("x_unit", C.c_void_p), ("y_unit", C.c_void_p), ("goal_rot", C.c_void_p),
+                ("reset_goal_buf", C.c_void_p)]
+
+
+class MdpInhandObsArgs(C.Structure):
+    """Mirror of ``mdp_inhand_obs_args_t``."""
+
+    _fields_ = [(n, C.c_void_p) for n in (
+        "joint_pos", "joint_vel", "lower", "upper", "object_root_state", "env_origins", "in_hand_pos", "goal_rot",
+        "body_state_w", "link_transforms", "link_velocities", "link_incoming_joint_force", "finger_bodies", "actions")] + [
+        ("action_dim", C.c_int32), ("force_torque_obs_scale", C.c_float),
+        ("policy_kind", C.c_int32), ("ld_policy", C.c_int32), ("policy", C.c_void_p),
+        ("critic_kind", C.c_int32), ("ld_critic", C.c_int32), ("critic", C.c_void_p),
+        ("partials", C.c_void_p), ("consecutive_successes", C.c_void_p), ("reset", C.c_void_p)]
+
+
+class MdpInhandReset(C.Structure):
+    """Mirror of ``mdp_inhand_reset_t``."""
+
+    _fields_ = [("goal", MdpInhandGoalReset),
+                ("reset_position_noise", C.c_float), ("reset_dof_pos_noise", C.c_float),
+                ("reset_dof_vel_noise", C.c_float), ("pad0", C.c_float),
+                ("object_default_root_state", C.c_void_p), ("env_origins", C.c_void_p),
+                ("object_root_state_w", C.c_void_p), ("sim_object_transforms", C.c_void_p),
+                ("sim_object_velocities", C.c_void_p),
+                ("default_joint_pos", C.c_void_p), ("default_joint_vel", C.c_void_p), ("lower", C.c_void_p),
+                ("upper", C.c_void_p),
+                ("prev_targets", C.c_void_p), ("cur_targets", C.c_void_p), ("hand_dof_targets", C.c_void_p),
+                ("joint_pos_target", C.c_void_p), ("ld_target", C.c_int32), ("ld_sim", C.c_int32),
+                ("joint_pos", C.c_void_p), ("joint_vel", C.c_void_p), ("prev_joint_vel", C.c_void_p),
+                ("joint_acc", C.c_void_p), ("sim_dof_positions", C.c_void_p), ("sim_dof_velocities", C.c_void_p),
+                ("successes", C.c_void_p), ("episode_length_buf", C.c_void_p)]
+
+
 class MdpSceneUpdate(C.Structure):
     """Mirror of ``mdp_scene_update_t``."""
 

@@ -21,7 +21,7 @@ class SyntheticPhysicsView:
               "link_velocities", "link_accelerations", "net_contact_forces")
 
     def __init__(self, num_envs: int, num_joints: int, num_bodies: int, device, num_contact_bodies: int | None = None,
-                 with_links: bool = True):
+                 with_links: bool = True, with_joint_forces: bool = False):
         self.count = num_envs
         self.num_joints = num_joints
         self.num_bodies = num_bodies
@@ -34,6 +34,8 @@ class SyntheticPhysicsView:
         }
         if with_links:
             shapes.update({"link_transforms": (n, b, 7), "link_velocities": (n, b, 6), "link_accelerations": (n, b, 6)})
+        if with_joint_forces:      # ArticulationView.get_link_incoming_joint_force() (inhand_manipulation_env.py:121)
+            shapes["link_incoming_joint_forces"] = (n, b, 6)
         self._shapes = shapes
         self._slices = {}
         off = 0
@@ -76,6 +78,7 @@ class SyntheticPhysicsView:
     def get_link_transforms(self): return self._field("link_transforms")
     def get_link_velocities(self): return self._field("link_velocities")
     def get_link_accelerations(self): return self._field("link_accelerations")
+    def get_link_incoming_joint_force(self): return self._field("link_incoming_joint_forces")
     def get_coms(self): return self.coms
     def get_net_contact_forces(self, dt: float | None = None): return self._field("net_contact_forces")
     def get_transforms(self): return self._field("root_transforms")

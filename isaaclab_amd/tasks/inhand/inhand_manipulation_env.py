@@ -6,7 +6,10 @@ kernel behind the C ABI (``mdp_inhand_*``).  ``consecutive_successes`` is the on
 (:424-431): its two partial sums are produced in fp64 per rank, optionally all-reduced (RCCL / gloo) and folded in
 by ``mdp_inhand_finish_rewards`` so the logged value is independent of how envs are sharded.
 Reset randomisation (``_reset_idx`` / ``_reset_target_pose``, :201-260) consumes the global torch generator in the
-reference and is kept on the host-visible torch path here (reset path is a "next" row).
+reference through ``nonzero()`` id lists (a host sync per step); here both are masked launches over the device generator
+(``mdp_inhand_reset_idx``, the goal reset inside ``mdp_inhand_dones_rewards_step``), so the whole step incl. resets is
+hipGraph-capturable.  ``inject_uniforms`` hands them recorded draws for parity tests.  The id-list forms
+(``_reset_idx(env_ids)``, ``_reset_target_pose(env_ids)``) are kept with the reference's signatures on the same kernels.
 """
 from __future__ import annotations
 
@@ -67,7 +70,8 @@ class InHandManipulationEnv:
         self.group = group              # torch.distributed process group for the sharded run (None = single rank)
         self.extras: dict = {}
         nj, nb = len(cfg.joint_names), len(cfg.body_names)
-        self.hand_view = SyntheticPhysicsView(n, nj, nb, device, num_contact_bodies=0)
+        self.hand_view = SyntheticPhysicsView(n, nj, nb, device, num_contact_bodies=0,
+                                              with_joint_forces=bool(cfg.asymmetric_obs))
         self.object_view = _ObjectView(n, device)
         self.hand = _Hand(cfg, self.hand_view, device)
         self.object = RigidObject(self.object_view, device)
@@ -114,6 +118,22 @@ class InHandManipulationEnv:
         self._obs = f(n, self.num_full_obs)
         self._goal_resets = torch.zeros(n, dtype=torch.bool, device=device)
         self._ccfg = self._make_cfg()
+        self._critic = f(n, self.num_full_state) if cfg.asymmetric_obs else None
+        if cfg.obs_type == "openai":
+            self._obs = f(n, self.num_reduced_obs)
+        # reset path: per-env generator epochs ({seed, epoch of env 0, ...}), injected uniforms for parity tests
+        self._reset_rng = torch.zeros(1 + n, dtype=torch.int64, device=device)
+        self._reset_rng[0] = int(getattr(cfg, "seed", 0) or 0) * 2654435761 % (1 << 62) + 12345
+        self._injected_u = None
+        # "masked": done envs are reset inside step() by masked launches (no host sync); "ids": the reference's
+        # nonzero() + _reset_idx(env_ids) (host sync); "off": the caller resets
+        self.auto_reset = "masked"
+        self.reset_goals = True            # :172-175 (the reference always does it)
+        # DirectRLEnv noise models (direct_rl_env.py:104-112)
+        self._action_noise_model = (cfg.action_noise_model.class_type(cfg.action_noise_model, n, device)
+                                    if getattr(cfg, "action_noise_model", None) else None)
+        self._observation_noise_model = (cfg.observation_noise_model.class_type(cfg.observation_noise_model, n, device)
+                                         if getattr(cfg, "observation_noise_model", None) else None)
         # DirectRLEnv.step's host statements around the five methods folded into their launches (mdp_inhand_*_to / _step /
         # _from_view, include/mdp_hip.h): same buffers, same values; False = one launch per reference statement
         self.fused_step = True
@@ -144,6 +164,29 @@ class InHandManipulationEnv:
     @property
     def num_full_obs(self) -> int:
         return 2 * self.num_hand_dofs + 13 + 11 + 13 * self.num_fingertips + self.cfg.action_space
+
+    @property
+    def num_reduced_obs(self) -> int:
+        return 3 * self.num_fingertips + 3 + 4 + self.cfg.action_space
+    @property
+    def num_full_state(self) -> int:
+        return self.num_full_obs + 6 * self.num_fingertips
+
+    def inject_uniforms(self, u: torch.Tensor | None) -> None:
+        """Parity tests: ``u`` (N, >= 7 + 2 * num_dofs) replaces the device generator of the reset path -- per env the
+        draws in the reference's order (goal 2 | position 3 | rotation 2 | dof positions D | dof velocities D); the goal
+        reset inside ``_get_rewards`` reads columns [0, 2)."""
+        self._injected_u = None if u is None else L.f32(u, "u").contiguous()
+
+    def _goal_reset_args(self, mask: torch.Tensor | None) -> L.MdpInhandGoalReset:
+        g = L.MdpInhandGoalReset()
+        g.env_mask = L.ptr(mask)
+        u = self._injected_u
+        g.injected_u, g.ld_injected = (L.ptr(u), u.stride(0)) if u is not None else (None, 0)
+        g.rng_state = L.ptr(self._reset_rng)
+        g.x_unit, g.y_unit = L.ptr(self.x_unit_tensor), L.ptr(self.y_unit_tensor)
+        g.goal_rot, g.reset_goal_buf = L.ptr(self.goal_rot), L.ptr(self.reset_goal_buf)
+        return g
 
     def _make_cfg(self) -> L.MdpInhandCfg:
         c, k = L.MdpInhandCfg(), self.cfg
@@ -239,7 +282,8 @@ class InHandManipulationEnv:
             L.ptr(self.successes), L.ptr(self.episode_length_buf), L.ptr(self.reset_terminated),
             L.ptr(self.reset_time_outs), L.ptr(self.reset_buf), L.ptr(xf), L.ptr(vel), L.ptr(self.actions),
             L.ptr(self.reset_goal_buf), L.ptr(self.reward_buf), L.ptr(self._partials),
-            C.byref(pend[0]) if pend is not None else None, float(pend[1]) if pend is not None else 0.0, L.stream()))
+            C.byref(pend[0]) if pend is not None else None, float(pend[1]) if pend is not None else 0.0,
+            C.byref(self._goal_reset_args(None)) if self.reset_goals else None, L.stream()))
         if self.group is not None:
             import torch.distributed as dist
 
@@ -289,44 +333,139 @@ class InHandManipulationEnv:
         self.extras["log"]["consecutive_successes"] = self.consecutive_successes.mean()
         return self.reward_buf
 
-    def compute_full_observations(self) -> torch.Tensor:
-        """:298-322"""
+    _OBS_KIND = {"full": 0, "openai": 1}      # MDP_INHAND_OBS_FULL / _REDUCED; the critic is MDP_INHAND_OBS_FULL_STATE (2)
+
+    def _observations_launch(self, policy_kind: int, policy: torch.Tensor | None, critic: torch.Tensor | None,
+                             reset_mask: torch.Tensor | None = None) -> None:
+        """``mdp_inhand_observations``: the policy layout and (asymmetric) ``compute_full_state`` in one launch; with
+        ``reset_mask`` the blocks first run ``_reset_idx`` for their envs of the mask (direct_rl_env.py:355-372)."""
+        a = L.MdpInhandObsArgs()
+        rst = None
+        if reset_mask is not None:
+            rst = self._reset_args(reset_mask)
+            a.reset = C.addressof(rst)
+        view = self.hand.root_physx_view
+        a.joint_pos, a.joint_vel = L.ptr(self.hand.data.joint_pos), L.ptr(self.hand.data.joint_vel)
+        a.lower, a.upper = L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits)
+        a.object_root_state, a.env_origins = L.ptr(self.object.data.root_state_w), L.ptr(self.scene.env_origins)
+        a.in_hand_pos, a.goal_rot = L.ptr(self.in_hand_pos), L.ptr(self.goal_rot)
         if self.fused_step:
-            view = self.hand.root_physx_view
-            finish, self._finish_pending = getattr(self, "_finish_pending", False), False
-            L.check(L.lib.mdp_inhand_full_obs_from_view(
-                C.byref(self._ccfg), L.ptr(self.hand.data.joint_pos), L.ptr(self.hand.data.joint_vel),
-                L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits), L.ptr(self.object.data.root_state_w),
-                L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
-                L.ptr(view.get_link_transforms()), L.ptr(view.get_link_velocities()), L.ptr(self._fingers),
-                L.ptr(self.actions), self.cfg.action_space, L.ptr(self._obs), self._obs.stride(0),
-                L.ptr(self._partials) if finish else None, L.ptr(self.consecutive_successes) if finish else None,
-                L.stream()))
-            return self._obs
-        L.check(L.lib.mdp_inhand_full_obs(C.byref(self._ccfg), L.ptr(self.hand.data.joint_pos),
-                                          L.ptr(self.hand.data.joint_vel), L.ptr(self.hand_dof_lower_limits),
-                                          L.ptr(self.hand_dof_upper_limits), L.ptr(self.object.data.root_state_w),
-                                          L.ptr(self.scene.env_origins), L.ptr(self.in_hand_pos), L.ptr(self.goal_rot),
-                                          L.ptr(self.hand.data.body_state_w), L.ptr(self._fingers), L.ptr(self.actions),
-                                          self.cfg.action_space, L.ptr(self._obs), self._obs.stride(0), L.stream()))
+            a.link_transforms, a.link_velocities = L.ptr(view.get_link_transforms()), L.ptr(view.get_link_velocities())
+        else:
+            a.body_state_w = L.ptr(self.hand.data.body_state_w)
+        a.finger_bodies, a.actions, a.action_dim = L.ptr(self._fingers), L.ptr(self.actions), self.cfg.action_space
+        a.force_torque_obs_scale = float(self.cfg.force_torque_obs_scale)
+        a.policy_kind, a.critic_kind = (policy_kind if policy is not None else -1), (2 if critic is not None else -1)
+        if policy is not None:
+            a.policy, a.ld_policy = L.ptr(policy), policy.stride(0)
+        if critic is not None:
+            # :121-123 fingertip_force_sensors = get_link_incoming_joint_force()[:, finger_bodies], gathered by the kernel
+            self.fingertip_force_sensors = view.get_link_incoming_joint_force()[:, self.finger_bodies]
+            a.link_incoming_joint_force = L.ptr(view.get_link_incoming_joint_force())
+            a.critic, a.ld_critic = L.ptr(critic), critic.stride(0)
+        finish, self._finish_pending = getattr(self, "_finish_pending", False), False
+        if finish:
+            a.partials, a.consecutive_successes = L.ptr(self._partials), L.ptr(self.consecutive_successes)
+        L.check(L.lib.mdp_inhand_observations(C.byref(self._ccfg), C.byref(a), L.stream()))
+        if rst is not None:
+            self._reset_noise_models(reset_mask)
+
+    def _policy_buffer(self, width: int) -> torch.Tensor:
+        if self._obs.shape[1] != width:
+            self._obs = torch.zeros(self.num_envs, width, dtype=torch.float32, device=self.device)
         return self._obs
 
-    def _get_observations(self) -> dict:
-        """:119-138 (``obs_type == "full"``, symmetric)"""
-        if self.cfg.obs_type != "full" or self.cfg.asymmetric_obs:
-            raise NotImplementedError("only obs_type='full' without asymmetric observations is lowered to HIP")
-        return {"policy": self.compute_full_observations()}
+    def compute_full_observations(self) -> torch.Tensor:
+        """:298-322"""
+        out = self._policy_buffer(self.num_full_obs)
+        self._observations_launch(0, out, None)
+        return out
+
+    def compute_reduced_observations(self) -> torch.Tensor:
+        """:281-296 (fingertip positions, object position, relative target orientation, actions)"""
+        out = self._policy_buffer(self.num_reduced_obs)
+        self._observations_launch(1, out, None)
+        return out
+
+    def compute_full_state(self) -> torch.Tensor:
+        """:324-350"""
+        if self._critic is None:
+            self._critic = torch.zeros(self.num_envs, self.num_full_state, dtype=torch.float32, device=self.device)
+        self._observations_launch(0, None, self._critic)
+        return self._critic
+
+    def _get_observations(self, reset_mask: torch.Tensor | None = None) -> dict:
+        """:119-138: policy layout by ``obs_type``; with ``asymmetric_obs`` the critic's ``compute_full_state`` comes out of
+        the same launch.  ``reset_mask`` (only ``step()`` passes it): the masked ``_reset_idx`` rides in that launch."""
+        if self.cfg.obs_type not in self._OBS_KIND:
+            raise ValueError(f"Unknown observations type: {self.cfg.obs_type!r}")    # the reference prints and fails later
+        kind = self._OBS_KIND[self.cfg.obs_type]
+        out = self._policy_buffer(self.num_full_obs if kind == 0 else self.num_reduced_obs)
+        if not self.cfg.asymmetric_obs:
+            self._observations_launch(kind, out, None, reset_mask)
+            return {"policy": out}
+        if self._critic is None:
+            self._critic = torch.zeros(self.num_envs, self.num_full_state, dtype=torch.float32, device=self.device)
+        self._observations_launch(kind, out, self._critic, reset_mask)
+        return {"policy": out, "critic": self._critic}
+
+    # -- reset path ----------------------------------------------------------------------------------------
+    def _ids_to_mask(self, env_ids) -> torch.Tensor | None:
+        if env_ids is None:
+            return None
+        mask = torch.zeros(self.num_envs, dtype=torch.bool, device=self.device)
+        mask[env_ids] = True
+        return mask
 
     def _reset_target_pose(self, env_ids):
-        """:248-260 (host torch path: consumes the global generator like the reference)."""
-        from ...utils.math import quat_from_angle_axis, quat_mul
+        """:248-260 for an id list (the reference's signature); the launch is the masked one."""
+        self._reset_target_pose_masked(self._ids_to_mask(env_ids))
 
-        k = len(env_ids)
-        rand = torch.rand((k, 2), device=self.device) * 2.0 - 1.0
-        new_rot = quat_mul(quat_from_angle_axis(rand[:, 0] * math.pi, self.x_unit_tensor[env_ids]),
-                           quat_from_angle_axis(rand[:, 1] * math.pi, self.y_unit_tensor[env_ids]))
-        self.goal_rot[env_ids] = new_rot
-        self.reset_goal_buf[env_ids] = False
+    def _reset_target_pose_masked(self, mask: torch.Tensor | None) -> None:
+        L.check(L.lib.mdp_inhand_reset_target_pose(C.byref(self._ccfg), C.byref(self._goal_reset_args(mask)), L.stream()))
+
+    def _reset_idx(self, env_ids):
+        """:201-246 + direct_rl_env.py:560-581 for an id list (the reference's signature)."""
+        self._reset_idx_masked(self._ids_to_mask(env_ids))
+
+    def _reset_idx_masked(self, mask: torch.Tensor | None) -> None:
+        """The same for the envs of a bool mask (None = all): one launch, no host synchronisation."""
+        a = self._reset_args(mask)
+        L.check(L.lib.mdp_inhand_reset_idx(C.byref(self._ccfg), C.byref(a), L.stream()))
+        self._reset_noise_models(mask)
+
+    def _reset_noise_models(self, mask: torch.Tensor | None) -> None:
+        """direct_rl_env.py:574-578"""
+        for model in (self._action_noise_model, self._observation_noise_model):
+            if model is not None:
+                model.reset_masked(mask)
+
+    def _reset_args(self, mask: torch.Tensor | None) -> L.MdpInhandReset:
+        """``mdp_inhand_reset_t`` over the env's buffers (the caller keeps the struct alive until its launch is queued)."""
+        if getattr(self, "_pending_update", None) is not None:
+            self._flush_hand_update()                       # the reset writes the joint buffers the update refreshes
+        hd, od, hv, ov = self.hand.data, self.object.data, self.hand.root_physx_view, self.object_view
+        a = L.MdpInhandReset()
+        a.goal = self._goal_reset_args(mask)
+        k = self.cfg
+        a.reset_position_noise, a.reset_dof_pos_noise = float(k.reset_position_noise), float(k.reset_dof_pos_noise)
+        a.reset_dof_vel_noise = float(k.reset_dof_vel_noise)
+        a.object_default_root_state, a.env_origins = L.ptr(od.default_root_state), L.ptr(self.scene.env_origins)
+        # write_root_pose_to_sim / write_root_velocity_to_sim: the data buffer (kept fresh) and the view's buffers
+        od._root_state_w.timestamp = od._sim_timestamp
+        a.object_root_state_w = L.ptr(od._root_state_w.data)
+        a.sim_object_transforms, a.sim_object_velocities = L.ptr(ov.get_transforms()), L.ptr(ov.get_root_velocities())
+        a.default_joint_pos, a.default_joint_vel = L.ptr(hd.default_joint_pos), L.ptr(hd.default_joint_vel)
+        a.lower, a.upper = L.ptr(self.hand_dof_lower_limits), L.ptr(self.hand_dof_upper_limits)
+        a.prev_targets, a.cur_targets = L.ptr(self.prev_targets), L.ptr(self.cur_targets)
+        a.hand_dof_targets = L.ptr(self.hand_dof_targets)
+        a.joint_pos_target, a.ld_target = L.ptr(self.hand.joint_pos_target), self.hand.joint_pos_target.stride(0)
+        q_sim, qd_sim = hv.get_dof_positions(), hv.get_dof_velocities()
+        a.joint_pos, a.joint_vel = L.ptr(hd.joint_pos), L.ptr(hd.joint_vel)
+        a.prev_joint_vel, a.joint_acc = L.ptr(hd._previous_joint_vel), L.ptr(hd.joint_acc)
+        a.sim_dof_positions, a.sim_dof_velocities, a.ld_sim = L.ptr(q_sim), L.ptr(qd_sim), q_sim.stride(0)
+        a.successes, a.episode_length_buf = L.ptr(self.successes), L.ptr(self.episode_length_buf)
+        return a
 
     def _defer_hand_update(self, dt: float) -> None:
         """``self.hand.data.update(dt)`` described now (the view's buffers of THIS sub-step) and executed by the next
@@ -354,8 +493,13 @@ class InHandManipulationEnv:
         self.hand.data.commit_scene_update(dt)
 
     # -- stepping (direct_rl_env.py:293-380) ------------------------------------------------------------
-    def step(self, action: torch.Tensor, reset_goals: bool = False):
-        self._pre_physics_step(action.to(self.device))
+    def step(self, action: torch.Tensor, reset_goals: bool | None = None):
+        if reset_goals is not None:
+            self.reset_goals = bool(reset_goals)
+        action = action.to(self.device)
+        if self._action_noise_model is not None:           # direct_rl_env.py:319-320
+            action = self._action_noise_model.apply(action)
+        self._pre_physics_step(action)
         for _ in range(self.cfg.decimation):
             self._sim_step_counter += 1
             self._apply_action()
@@ -367,18 +511,28 @@ class InHandManipulationEnv:
             self.object.update(self.physics_dt)
         self.common_step_counter += 1
         if self.fused_step:
-            self._dones_rewards_step()
+            self._dones_rewards_step()                     # incl. the goal reset of _get_rewards (:172-175)
         else:
             self.episode_length_buf += 1
             terminated, time_outs = self._get_dones()
             self.reset_terminated[:] = terminated
             self.reset_time_outs[:] = time_outs
             torch.logical_or(self.reset_terminated, self.reset_time_outs, out=self.reset_buf)
-        if not self.fused_step:
             self.reward_buf = self._get_rewards()
-        if reset_goals:                                    # :172-175 (host sync, like the reference)
-            goal_env_ids = self.reset_goal_buf.nonzero(as_tuple=False).squeeze(-1)
-            if len(goal_env_ids) > 0:
-                self._reset_target_pose(goal_env_ids)
-        self.obs_buf = self._get_observations()
+            if self.reset_goals:                           # :172-175, masked: no nonzero()
+                self._reset_target_pose_masked(self.reset_goal_buf)
+        # direct_rl_env.py:355-364
+        reset_mask = None
+        if self.auto_reset == "masked":
+            if self.fused_step:
+                reset_mask = self.reset_buf                # rides in the observation launch
+            else:
+                self._reset_idx_masked(self.reset_buf)
+        elif self.auto_reset == "ids":
+            reset_env_ids = self.reset_buf.nonzero(as_tuple=False).squeeze(-1)
+            if len(reset_env_ids) > 0:
+                self._reset_idx(reset_env_ids)
+        self.obs_buf = self._get_observations(reset_mask)
+        if self._observation_noise_model is not None:      # direct_rl_env.py:376-377 (policy only, never the critic)
+            self.obs_buf["policy"] = self._observation_noise_model.apply(self.obs_buf["policy"])
         return self.obs_buf, self.reward_buf, self.reset_terminated, self.reset_time_outs, self.extras

@@ -3,6 +3,7 @@ reads.  USD assets, spawn / physics properties and markers are out of scope."""
 from __future__ import annotations
 
 from ...utils.configclass import configclass
+from ...utils.noise import GaussianNoiseCfg, NoiseModelWithAdditiveBiasCfg
 
 # joint / body names of the Shadow hand in PhysX order (24 DoF, 26 bodies): the MDP path only resolves the actuated
 # joints and the fingertip bodies by name (inhand_manipulation_env.py:44-56)
@@ -63,3 +64,32 @@ class ShadowHandEnvCfg:
     av_factor: float = 0.1
     act_moving_average: float = 1.0
     force_torque_obs_scale: float = 10.0
+    # DirectRLEnvCfg (direct_rl_env_cfg.py): noise models applied by DirectRLEnv.step (direct_rl_env.py:319-320, 376-377)
+    action_noise_model: object = None
+    observation_noise_model: object = None
+    seed: int = 0
+
+
+@configclass
+class ShadowHandOpenAIEnvCfg(ShadowHandEnvCfg):
+    """:228-283.  The ``events`` of the reference cfg randomise physics properties (materials, masses, gains, gravity):
+    physics side, out of scope."""
+    decimation: int = 3
+    episode_length_s: float = 8.0
+    observation_space: int = 42
+    state_space: int = 187
+    asymmetric_obs: bool = True
+    obs_type: str = "openai"
+    sim_dt: float = 1 / 60
+    fall_penalty: float = -50
+    success_tolerance: float = 0.4
+    max_consecutive_success: int = 50
+    act_moving_average: float = 0.3
+    action_noise_model: object = NoiseModelWithAdditiveBiasCfg(
+        noise_cfg=GaussianNoiseCfg(mean=0.0, std=0.05, operation="add"),
+        bias_noise_cfg=GaussianNoiseCfg(mean=0.0, std=0.015, operation="abs"),
+    )
+    observation_noise_model: object = NoiseModelWithAdditiveBiasCfg(
+        noise_cfg=GaussianNoiseCfg(mean=0.0, std=0.002, operation="add"),
+        bias_noise_cfg=GaussianNoiseCfg(mean=0.0, std=0.0001, operation="abs"),
+    )

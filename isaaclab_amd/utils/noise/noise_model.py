@@ -45,6 +45,10 @@ class NoiseModel:
     def reset(self, env_ids: Sequence[int] | None = None):
         pass
 
+    def reset_masked(self, mask: torch.Tensor | None) -> None:
+        """``reset`` for the envs of a device bool mask (None = all): no id list, no host synchronisation."""
+        pass
+
     def apply(self, data: torch.Tensor) -> torch.Tensor:
         return self._noise_model_cfg.noise_cfg.func(data, self._noise_model_cfg.noise_cfg)
 
@@ -59,6 +63,15 @@ class NoiseModelWithAdditiveBias(NoiseModel):
         if env_ids is None:
             env_ids = slice(None)
         self._bias[env_ids] = self._bias_noise_cfg.func(self._bias[env_ids], self._bias_noise_cfg)
+
+    def reset_masked(self, mask: torch.Tensor | None) -> None:
+        # the bias of every env is drawn and kept only where the mask is set: same distribution as the id-list form,
+        # the selection stays on the device
+        fresh = self._bias_noise_cfg.func(self._bias, self._bias_noise_cfg)
+        if mask is None:
+            self._bias.copy_(fresh)
+        else:
+            torch.where(mask.view(-1, 1), fresh, self._bias, out=self._bias)
 
     def apply(self, data: torch.Tensor) -> torch.Tensor:
         from ..._terms import make_term, run_obs_single

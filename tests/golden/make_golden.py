@@ -893,6 +893,126 @@ def gen_inhand():
     save("inhand", **out)
 
 
+def gen_inhand_reset():
+    """The rest of the in-hand env, run by the REFERENCE methods on an uninitialised instance with duck-typed assets:
+    compute_reduced_observations (:281-296), compute_full_state (:324-350), _reset_target_pose (:248-260) and _reset_idx
+    (:201-246, with the real RigidObject.write_root_*_to_sim / Articulation.write_joint_state_to_sim /
+    set_joint_position_target behind it) -- torch.rand replaced by recorded draws."""
+    ih = R.ref_inhand()
+    art = R.ref_import("isaaclab.assets.articulation.articulation")
+    rig = R.ref_import("isaaclab.assets.rigid_object.rigid_object")
+    # the env module was loaded against the name-only stub of isaaclab.envs, so `super()._reset_idx` has nothing to find:
+    # import the real DirectRLEnv (a few more name-only stubs for its UI imports) and lend its _reset_idx to the stub base
+    R.install_stubs()
+    for name in ("omni.kit.commands", "omni.ui", "isaaclab.envs.ui", "omni.kit.viewport", "omni.kit.viewport.utility",
+                 "isaacsim.core.utils.viewports"):
+        R._stub(name)
+    direct = R.ref_import("isaaclab.envs.direct_rl_env")
+    ih.InHandManipulationEnv.__mro__[1]._reset_idx = direct.DirectRLEnv._reset_idx
+    g = torch.Generator().manual_seed(2024)
+    out = {}
+
+    class View:
+        def __init__(self):
+            self.calls = {}
+
+        def __getattr__(self, name):
+            if name.startswith("set_"):
+                def f(data, indices=None):
+                    self.calls[name] = (data.clone(), None if indices is None else torch.as_tensor(indices).clone())
+                return f
+            raise AttributeError(name)
+
+    for n in (7, 48):
+        p = f"n{n}_"
+        D, Fg, B, A = 24, 5, 26, 20
+        origins = torch.randn(n, 3, generator=g) * 3.0
+        obj = torch.zeros(n, 13)
+        obj[:, :3] = torch.randn(n, 3, generator=g) * 0.05 + torch.tensor([0.0, -0.39, 0.6]) + origins
+        obj[:, 3:7] = rand_quat(g, n)
+        obj[:, 7:] = torch.randn(n, 6, generator=g)
+        goal = rand_quat(g, n)
+        in_hand = torch.tensor([0.0, -0.39, 0.56]).repeat(n, 1)
+        actions = torch.rand(n, A, generator=g) * 2 - 1
+        lower = -1.0 - torch.rand(n, D, generator=g)
+        upper = 1.0 + torch.rand(n, D, generator=g)
+        q = lower + (upper - lower) * torch.rand(n, D, generator=g)
+        qd = torch.randn(n, D, generator=g)
+        body = torch.randn(n, B, 13, generator=g)
+        forces = torch.randn(n, B, 6, generator=g)
+        fingers = sorted(torch.randperm(B, generator=g)[:Fg].tolist())
+        env = object.__new__(ih.InHandManipulationEnv)
+        env.cfg = _NS(vel_obs_scale=0.2, force_torque_obs_scale=10.0, reset_position_noise=0.01, reset_dof_pos_noise=0.2,
+                      reset_dof_vel_noise=0.3, events=None, action_noise_model=None, observation_noise_model=None)
+        env.num_envs, env.num_fingertips, env.finger_bodies, env.actions, env.device = n, Fg, fingers, actions, "cpu"
+        env.num_hand_dofs = D
+        hand_data = _NS(body_pos_w=body[..., :3].clone(), body_quat_w=body[..., 3:7], body_vel_w=body[..., 7:13],
+                        joint_pos=q.clone(), joint_vel=qd.clone(), default_joint_pos=torch.randn(n, D, generator=g) * 0.3,
+                        default_joint_vel=torch.randn(n, D, generator=g) * 0.1, joint_pos_target=torch.randn(n, D, generator=g),
+                        _previous_joint_vel=torch.randn(n, D, generator=g), joint_acc=torch.randn(n, D, generator=g),
+                        _body_state_w=_NS(timestamp=1.0), _body_link_state_w=_NS(timestamp=1.0), _body_com_state_w=_NS(timestamp=1.0))
+        hand = _NS(data=hand_data, _data=hand_data, device="cpu", root_physx_view=View(), _ALL_INDICES=torch.arange(n),
+                   num_joints=D)
+        for name in ("write_joint_state_to_sim", "set_joint_position_target"):
+            setattr(hand, name, types.MethodType(getattr(art.Articulation, name), hand))
+        obj_data = _NS(root_pos_w=obj[:, :3], root_quat_w=obj[:, 3:7], root_vel_w=obj[:, 7:13], root_lin_vel_w=obj[:, 7:10],
+                       root_ang_vel_w=obj[:, 10:13], root_state_w=obj.clone(),
+                       default_root_state=torch.cat([torch.tensor([0.0, -0.39, 0.6]).repeat(n, 1), rand_quat(g, n),
+                                                     torch.randn(n, 6, generator=g)], dim=1),
+                       body_acc_w=torch.randn(n, 1, 6, generator=g))
+        cube = _NS(data=obj_data, _data=obj_data, device="cpu", root_physx_view=View(), _ALL_INDICES=torch.arange(n))
+        for name in ("write_root_pose_to_sim", "write_root_velocity_to_sim"):
+            setattr(cube, name, types.MethodType(getattr(rig.RigidObject, name), cube))
+        env.hand, env.object, env.scene = hand, cube, _NS(env_origins=origins, reset=lambda env_ids: None)
+        env.hand_dof_lower_limits, env.hand_dof_upper_limits = lower, upper
+        env.in_hand_pos, env.goal_rot = in_hand, goal.clone()
+        env.goal_pos = torch.zeros(n, 3)
+        env.x_unit_tensor = torch.tensor([1.0, 0, 0]).repeat(n, 1)
+        env.y_unit_tensor = torch.tensor([0, 1.0, 0]).repeat(n, 1)
+        env.fingertip_force_sensors = forces[:, fingers]
+        ih.InHandManipulationEnv._compute_intermediate_values(env)
+        out.update({p + "origins": origins, p + "obj": obj, p + "goal": goal, p + "in_hand": in_hand, p + "actions": actions,
+                    p + "lower": lower, p + "upper": upper, p + "q": q, p + "qd": qd, p + "body": body, p + "forces": forces,
+                    p + "fingers": torch.tensor(fingers),
+                    p + "reduced_obs": ih.InHandManipulationEnv.compute_reduced_observations(env),
+                    p + "full_state": ih.InHandManipulationEnv.compute_full_state(env)})
+        # -- _reset_target_pose for a subset
+        ids = torch.tensor(sorted(torch.randperm(n, generator=g)[: max(2, n // 3)].tolist()))
+        u = torch.rand(n, 7 + 2 * D, generator=g)
+        env.reset_goal_buf = torch.rand(n, generator=g) < 0.5
+        out.update({p + "ids": ids, p + "u": u, p + "reset_goal_in": env.reset_goal_buf.clone()})
+        with _RandQueue(rand=[u[ids, :2]]):
+            ih.InHandManipulationEnv._reset_target_pose(env, ids)
+        out.update({p + "goal_after_target_pose": env.goal_rot.clone(), p + "reset_goal_after_target_pose": env.reset_goal_buf.clone()})
+        # -- _reset_idx for another subset (InHandManipulationEnv._reset_idx -> the real DirectRLEnv._reset_idx)
+        ids2 = torch.tensor(sorted(torch.randperm(n, generator=g)[: max(2, n // 2)].tolist()))
+        env.goal_rot = goal.clone()
+        env.reset_goal_buf = out[p + "reset_goal_in"].clone()
+        env.prev_targets, env.cur_targets, env.hand_dof_targets = (torch.randn(n, D, generator=g) for _ in range(3))
+        env.successes = torch.randint(0, 5, (n,), generator=g).float()
+        env.episode_length_buf = torch.randint(1, 500, (n,), generator=g)
+        env._compute_intermediate_values = lambda: None
+        out.update({p + "ids2": ids2, p + "object_default": obj_data.default_root_state.clone(),
+                    p + "default_joint_pos": hand_data.default_joint_pos.clone(), p + "default_joint_vel": hand_data.default_joint_vel.clone(),
+                    p + "in_prev_targets": env.prev_targets.clone(), p + "in_cur_targets": env.cur_targets.clone(),
+                    p + "in_hand_dof_targets": env.hand_dof_targets.clone(), p + "in_joint_pos_target": hand_data.joint_pos_target.clone(),
+                    p + "in_prev_joint_vel": hand_data._previous_joint_vel.clone(), p + "in_joint_acc": hand_data.joint_acc.clone(),
+                    p + "in_successes": env.successes.clone(), p + "in_ep": env.episode_length_buf.clone()})
+        with _RandQueue(rand=[u[ids2, 0:2], u[ids2, 2:5], u[ids2, 5:7], u[ids2, 7:7 + D], u[ids2, 7 + D:]]):
+            ih.InHandManipulationEnv._reset_idx(env, ids2)
+        out.update({p + "r_goal": env.goal_rot, p + "r_reset_goal": env.reset_goal_buf, p + "r_object_state": obj_data.root_state_w,
+                    p + "r_sim_transforms": cube.root_physx_view.calls["set_transforms"][0],
+                    p + "r_sim_velocities": cube.root_physx_view.calls["set_velocities"][0],
+                    p + "r_prev_targets": env.prev_targets, p + "r_cur_targets": env.cur_targets,
+                    p + "r_hand_dof_targets": env.hand_dof_targets, p + "r_joint_pos_target": hand_data.joint_pos_target,
+                    p + "r_joint_pos": hand_data.joint_pos, p + "r_joint_vel": hand_data.joint_vel,
+                    p + "r_prev_joint_vel": hand_data._previous_joint_vel, p + "r_joint_acc": hand_data.joint_acc,
+                    p + "r_sim_dof_pos": hand.root_physx_view.calls["set_dof_positions"][0],
+                    p + "r_sim_dof_vel": hand.root_physx_view.calls["set_dof_velocities"][0],
+                    p + "r_successes": env.successes, p + "r_ep": env.episode_length_buf})
+    save("inhand_reset", **out)
+
+
 class _RandQueue:
     """Replaces torch.rand / torch.randint_like while a reference function runs: hands out the prepared tensors in call
     order (shape-checked), so the reference consumes exactly the numbers the fixture records."""
@@ -1474,9 +1594,9 @@ def gen_samplers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "events", "terrains", "imu", "frames", "camera", "samplers", "camera_class", "mesh_terrains"]
+    which = sys.argv[1:] or ["math", "actuators", "buffers", "terms", "managers", "sensors", "command", "inhand", "inhand_reset", "events", "terrains", "imu", "frames", "camera", "samplers", "camera_class", "mesh_terrains"]
     table = {"math": gen_math, "actuators": gen_actuators, "buffers": gen_buffers_noise_modifiers, "terms": gen_terms,
-             "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand,
+             "managers": gen_managers, "sensors": gen_sensors_state, "command": gen_command_action, "inhand": gen_inhand, "inhand_reset": gen_inhand_reset,
              "events": gen_events, "terrains": gen_terrains, "mesh_terrains": gen_mesh_terrains, "imu": gen_imu,
              "frames": gen_frame_transformer, "camera": gen_camera, "camera_class": gen_camera_class, "samplers": gen_samplers}
     for w in which:
