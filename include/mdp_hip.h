@@ -747,6 +747,11 @@ int mdp_stats_moments(const float* x, int num_envs, int dim, int ld, double* out
  * out[2*k] = sum_{mask} values[k][env], out[2*k+1] = count, for k rows of a (K,N) matrix. */
 int mdp_stats_masked_sums(const float* values, int rows, int num_envs, const uint8_t* mask, double* out,
                           void* stream);
+/* The same over rows of another element type -- elem_kind 0: float, 1: uint8 (per-term done flags:
+ * `Episode_Termination/<term>` = count_nonzero over the reset envs, termination_manager.py:142-144), 2: int64 (terrain
+ * levels: `Curriculum/terrain_levels` = mean over ALL envs, TASKS/.../velocity/mdp/curriculums.py:55, mask NULL). */
+int mdp_stats_masked_sums_typed(const void* values, int elem_kind, int rows, int num_envs, const uint8_t* mask,
+                                double* out, void* stream);
 
 /* Reset of per-env state by MASK instead of by id list, many buffers in ONE launch (the `buf[env_ids] = value` lines of
  * ManagerBasedRLEnv._reset_idx's callees: sensor_base.py:192-195, contact_sensor.py:143-155, action_manager.py reset,

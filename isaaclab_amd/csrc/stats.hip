@@ -44,7 +44,8 @@ __global__ void k_moments(const float* __restrict__ x, int N, int D, int ld, dou
     }
 }
 
-__global__ void k_masked_sums(const float* __restrict__ v, int rows, int N, const uint8_t* __restrict__ mask,
+template <typename T>
+__global__ void k_masked_sums(const T* __restrict__ v, int rows, int N, const uint8_t* __restrict__ mask,
                               double* __restrict__ out) {
     int k = blockIdx.x;
     __shared__ double rs[256];
@@ -52,15 +53,15 @@ __global__ void k_masked_sums(const float* __restrict__ v, int rows, int N, cons
     double s = 0.0, c = 0.0;
     // eight elements per trip, their loads issued before the first add (with a branch per element every load is its own
     // round trip, N / 256 of them per thread); a masked-out element adds an exact zero: same order, same sums
-    const float* row = v + (int64_t)k * N;
+    const T* row = v + (int64_t)k * N;
     for (int e0 = threadIdx.x; e0 < N; e0 += 8 * blockDim.x) {
-        float x[8];
+        T x[8];
         uint8_t m[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int e = e0 + j * blockDim.x;
             const bool in = e < N;
-            x[j] = in ? row[e] : 0.0f;
+            x[j] = in ? row[e] : (T)0;
             m[j] = in ? (mask ? mask[e] : (uint8_t)1) : (uint8_t)0;
         }
 #pragma unroll
@@ -346,7 +347,23 @@ extern "C" int mdp_stats_masked_sums(const float* values, int rows, int num_envs
                                      void* stream) {
     MDP_REQUIRE(values && out, "null pointer");
     if (rows == 0) return MDP_OK;
-    hipLaunchKernelGGL(k_masked_sums, dim3(rows), dim3(256), 0, as_stream(stream), values, rows, num_envs, mask, out);
+    hipLaunchKernelGGL(k_masked_sums<float>, dim3(rows), dim3(256), 0, as_stream(stream), values, rows, num_envs, mask, out);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_stats_masked_sums_typed(const void* values, int elem_kind, int rows, int num_envs, const uint8_t* mask,
+                                           double* out, void* stream) {
+    MDP_REQUIRE(values && out, "null pointer");
+    MDP_REQUIRE(elem_kind >= 0 && elem_kind <= 2, "unknown element kind %d", elem_kind);
+    if (rows == 0) return MDP_OK;
+    hipStream_t st = as_stream(stream);
+    if (elem_kind == 0)
+        hipLaunchKernelGGL(k_masked_sums<float>, dim3(rows), dim3(256), 0, st, (const float*)values, rows, num_envs, mask, out);
+    else if (elem_kind == 1)
+        hipLaunchKernelGGL(k_masked_sums<uint8_t>, dim3(rows), dim3(256), 0, st, (const uint8_t*)values, rows, num_envs, mask, out);
+    else
+        hipLaunchKernelGGL(k_masked_sums<int64_t>, dim3(rows), dim3(256), 0, st, (const int64_t*)values, rows, num_envs, mask, out);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

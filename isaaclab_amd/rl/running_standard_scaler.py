@@ -63,14 +63,39 @@ class RunningStandardScaler:
                                                 self._partial.data_ptr(), L.stream(self.device)))
         parts = self._partial
         if dist is not None and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            gathered = [torch.empty_like(parts) for _ in range(dist.get_world_size(self.group))]
-            dist.all_gather(gathered, parts, group=self.group)
-            parts = torch.cat(gathered)
+            # one all-reduce(sum) of this rank's additive row about the shared running mean (distributed.shifted_sums):
+            # the same collective shape as the episode statistics, which FusedStatistics packs behind it
+            from ..distributed import shifted_sums
+
+            row = shifted_sums(parts, self.running_mean)
+            dist.all_reduce(row, op=dist.ReduceOp.SUM, group=self.group)
+            self.apply_merged_row(row)
+            return
+        self._update_from(parts)
+
+    def _update_from(self, parts: torch.Tensor):
         # merge + running update + fp32 casts: one launch, the statistics never leave the device
         L.check(L.lib.mdp_scaler_update(parts.shape[0], self.size, parts.data_ptr(), self.running_mean.data_ptr(),
                                         self.running_variance.data_ptr(), self.current_count.data_ptr(), self.epsilon,
                                         self._mean32.data_ptr(), self._std32.data_ptr(), self._denom.data_ptr(),
                                         L.stream(self.device)))
+
+    def local_row(self, x: torch.Tensor) -> torch.Tensor:
+        """This rank's batch as ONE additive fp64 row ``[n, sum (x - c), sum (x - c)^2]``, c = the running mean
+        (``FusedStatistics`` packs it in front of the episode statistics)."""
+        from ..distributed import shifted_sums
+
+        rows, ld = self._rows(x, self.size, "x")
+        L.check(L.lib.mdp_stats_moments_chunked(x.data_ptr(), rows, self.size, ld, self.num_chunks,
+                                                self._partial.data_ptr(), L.stream(self.device)))
+        return shifted_sums(self._partial, self.running_mean)
+
+    def apply_merged_row(self, row: torch.Tensor):
+        """Running update from the additive row summed over every rank."""
+        from ..distributed import chan_row_from_shifted
+
+        self._merged = chan_row_from_shifted(row, self.running_mean).contiguous()   # kept until the launch has read it
+        self._update_from(self._merged)
 
     def forward(self, x: torch.Tensor, train: bool = False, inverse: bool = False, no_grad: bool = True,
                 out: torch.Tensor | None = None) -> torch.Tensor:

@@ -26,6 +26,15 @@ def _data():
     return obs, sums, mask, succ, resets
 
 
+def _term_data():
+    rng = np.random.RandomState(78)
+    return rng.rand(2, N) < 0.3, rng.randint(0, 10, N).astype(np.int64)
+
+
+def _extra_batch():
+    return (np.random.RandomState(79).randn(N, D) * 0.8 - 1.1).astype(np.float32)
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -49,15 +58,26 @@ def _rank_main(rank, port, out_dir):
         x = obs[t, lo:hi].astype(np.float64)
         part = np.concatenate([[hi - lo], x.sum(0), ((x - x.mean(0)) ** 2).sum(0)])
         norm.merge_partial(torch.from_numpy(part))
-    # (2) episode statistics: packed [sum, count] pairs, one all-reduce
-    payload = torch.zeros(2 * K, dtype=torch.float64)
+    # (2) episode statistics, all four families of SURVEY 8e(2) as packed [sum, count] pairs -- and in the SAME vector,
+    # in front of them, the normaliser's additive row of one more batch: ONE all-reduce for everything (FusedStatistics'
+    # layout; the per-rank partials are numpy here, HIP kernels on a GPU rank)
+    names = ([f"Episode_Reward/r{k}" for k in range(K - 1)] + ["Metrics/base_velocity/error_vel_xy"]
+             + ["Episode_Termination/time_out", "Episode_Termination/base_contact", "Curriculum/terrain_levels"])
+    term_flags, levels = _term_data()
     m = mask[lo:hi]
+    pairs = []
     for k in range(K):
-        payload[2 * k] = float(sums[k, lo:hi].astype(np.float64)[m].sum())
-        payload[2 * k + 1] = float(m.sum())
-    work = D_.allreduce_payload(payload, WORLD)
+        pairs += [float(sums[k, lo:hi].astype(np.float64)[m].sum()), float(m.sum())]
+    for t in range(2):                                    # count_nonzero over the reset envs (termination_manager.py:142-144)
+        pairs += [float(term_flags[t, lo:hi][m].sum()), float(m.sum())]
+    pairs += [float(levels[lo:hi].sum()), float(hi - lo)]  # mean level over ALL envs (curriculums.py:55)
+    x = _extra_batch()[lo:hi].astype(np.float64)
+    part = torch.from_numpy(np.concatenate([[hi - lo], x.sum(0), ((x - x.mean(0)) ** 2).sum(0)]))
+    fused = torch.cat([norm.local_row(part), torch.tensor(pairs, dtype=torch.float64)])
+    work = D_.allreduce_payload(fused, WORLD)
     work.wait()
-    names = [f"Episode_Reward/r{k}" for k in range(K - 1)] + ["Metrics/base_velocity/error_vel_xy"]
+    norm.fold(fused[: 1 + 2 * D])
+    payload = fused[1 + 2 * D :]
     stats = D_.finalize_stats(names, payload, 20.0)
     # (3) Shadow hand: [sum resets, sum successes*resets] (inhand_manipulation_env.py:424-431)
     partials = torch.tensor([float(resets[lo:hi].sum()), float((succ[lo:hi] * resets[lo:hi]).sum())], dtype=torch.float64)
@@ -93,8 +113,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     # single-process reference of the same running update (my_running_standard_scaler.py:57-80: count starts at 1,
     # mean 0, var 1; batch variance is torch.var of the merged batch, Bessel-corrected)
     mean, var, count = np.zeros(D), np.ones(D), 1.0
-    for t in range(obs.shape[0]):
-        x = obs[t].astype(np.float64)
+    for x in [obs[t].astype(np.float64) for t in range(obs.shape[0])] + [_extra_batch().astype(np.float64)]:
         bm, bv, bn = x.mean(0), x.var(0, ddof=1), float(N)
         delta, tot = bm - mean, count + bn
         m2 = var * count + bv * bn + delta ** 2 * count * bn / tot
@@ -105,6 +124,8 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
         assert float(r[k]["count"]) == count
     exp = [sums[k].astype(np.float64)[mask].sum() / mask.sum() for k in range(K)]
     exp = [e / 20.0 for e in exp[:-1]] + [exp[-1]]     # episodic reward sums are divided by the episode length in s
+    term_flags, levels = _term_data()
+    exp += [float(term_flags[0][mask].sum()), float(term_flags[1][mask].sum()), float(levels.mean())]
     for k in range(WORLD):
         np.testing.assert_allclose(r[k]["stats"], exp, rtol=1e-12)
         np.testing.assert_array_equal(r[k]["partials"], [resets.sum(), (succ * resets).sum()])
