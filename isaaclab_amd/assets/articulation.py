@@ -205,8 +205,10 @@ class Articulation:
         per (env, joint) element with per-element parameters, so ``_apply_actuator_model`` (articulation.py:1399-1436)
         runs them as one launch over the full (N, J) buffers writing ``computed_torque`` / ``applied_torque`` in place,
         instead of a gather of five inputs, a launch and a scatter of six outputs per group.  The groups stay in
-        ``self.actuators`` with their own parameters; their ``computed_effort`` / ``applied_effort`` read through to the
-        merged buffers.  Call ``refresh_merged_actuator_parameters()`` after editing a group's gains or limits."""
+        ``self.actuators`` with their own parameters (edits of a group's gains or limits are picked up by the next step,
+        see ``_step_actuators``); a group's ``computed_effort`` / ``applied_effort`` are READ-ONLY gathers of its columns
+        of the merged outputs -- a fresh tensor per access, so writes to them and pointers taken from them do not reach
+        the articulation: use ``data.computed_torque`` / ``data.applied_torque`` for that."""
         acts = list(self.actuators.values())
         if len(acts) < 2:
             return
@@ -241,17 +243,31 @@ class Articulation:
             a._merged_into = merged
         self._single_full_group = True
 
+    _MERGED_PARAMS = ("stiffness", "damping", "armature", "friction", "effort_limit", "velocity_limit")
+
+    def _group_param_versions(self) -> tuple:
+        """Identity and in-place version counter of every group parameter tensor: changes when a caller edits a group's
+        gains or limits in place (``actuator.stiffness[env_ids] = ...``, the reference's randomize_actuator_gains
+        pattern) or rebinds the attribute.  Host-only bookkeeping, no launch."""
+        return tuple((id(t), t._version) for a in self.actuators.values()
+                     for t in (getattr(a, name) for name in self._MERGED_PARAMS))
+
     def refresh_merged_actuator_parameters(self):
+        """Copies the groups' parameters into the merged (N, J) buffers.  ``_step_actuators`` calls it by itself when a
+        group's parameter tensor was modified since the last copy."""
         m = self._merged_actuator
         if m is None:
             return
         for a in self.actuators.values():
-            for name in ("stiffness", "damping", "armature", "friction", "effort_limit", "velocity_limit"):
+            for name in self._MERGED_PARAMS:
                 getattr(m, name)[:, a.joint_indices] = getattr(a, name)
+        self._merged_versions = self._group_param_versions()
 
     def _step_actuators(self) -> list:
         """The actuator objects ``_apply_actuator_model`` evaluates: the merged one, else every group."""
         if getattr(self, "_merged_actuator", None) is not None:
+            if self._group_param_versions() != getattr(self, "_merged_versions", None):
+                self.refresh_merged_actuator_parameters()      # a group's gains / limits were edited: pick them up
             return [self._merged_actuator]
         return list(self.actuators.values())
 

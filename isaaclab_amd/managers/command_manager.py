@@ -33,31 +33,51 @@ class CommandTerm(ManagerTermBase):
         return False
 
     def reset(self, env_ids: Sequence[int] | None = None) -> dict[str, float]:
-        """command_manager.py:120-149 (generic path; subclasses may fuse it)."""
-        if env_ids is None:
-            env_ids = slice(None)
-        extras = {}
-        for metric_name, metric_value in self.metrics.items():
-            extras[metric_name] = torch.mean(metric_value[env_ids]).item()
-            metric_value[env_ids] = 0.0
-        self.command_counter[env_ids] = 0
-        self._resample(env_ids)
-        return extras
+        """Episode end of ``env_ids`` (contract: command_manager.py:120-149): report the mean of every metric over those
+        envs, clear metrics and resample counters, draw a new command.  The means come back to the host together (one
+        transfer for all metrics); fused subclasses keep even that on the device."""
+        rows = slice(None) if env_ids is None else env_ids
+        names = list(self.metrics)
+        means = torch.stack([self.metrics[k][rows].mean() for k in names]).tolist() if names else []
+        for k in names:
+            self.metrics[k][rows] = 0.0
+        self.command_counter[rows] = 0
+        self._resample(rows)
+        return dict(zip(names, means))
 
     def compute(self, dt: float):
-        """command_manager.py:151-166 (generic path with the reference's host sync; fused subclasses override)."""
+        """One env step of the generator (contract: command_manager.py:151-166): metrics, countdown, a new command where
+        the countdown ran out, then the per-step command update."""
         self._update_metrics()
         self.time_left -= dt
-        resample_env_ids = (self.time_left <= 0.0).nonzero().flatten()
-        if len(resample_env_ids) > 0:
-            self._resample(resample_env_ids)
+        self._resample_where(self.time_left <= 0.0)
         self._update_command()
 
-    def _resample(self, env_ids: Sequence[int]):
-        if isinstance(env_ids, slice) or len(env_ids) != 0:
-            self.time_left[env_ids] = self.time_left[env_ids].uniform_(*self.cfg.resampling_time_range)
-            self.command_counter[env_ids] += 1
+    def _resample_where(self, expired: torch.Tensor) -> None:
+        """Resampling for the envs of a device mask.  Countdown and counter are selected on the device; a term that
+        implements ``_resample_command_masked(mask)`` never leaves it.  Terms that only have the reference's
+        ``_resample_command(env_ids)`` get their id list from one ``nonzero()`` (the host sync the reference pays too)."""
+        lo, hi = self.cfg.resampling_time_range
+        fresh = torch.empty_like(self.time_left).uniform_(lo, hi)
+        torch.where(expired, fresh, self.time_left, out=self.time_left)
+        self.command_counter += expired
+        masked = getattr(self, "_resample_command_masked", None)
+        if masked is not None:
+            masked(expired)
+            return
+        env_ids = expired.nonzero().flatten()
+        if env_ids.numel() > 0:
             self._resample_command(env_ids)
+
+    def _resample(self, env_ids: Sequence[int]):
+        """The id-list form the reference exposes (``slice`` or ids; nothing happens for an empty list)."""
+        if not isinstance(env_ids, slice) and len(env_ids) == 0:
+            return
+        lo, hi = self.cfg.resampling_time_range
+        count = self.time_left[env_ids].shape
+        self.time_left[env_ids] = torch.empty(count, device=self.device).uniform_(lo, hi)
+        self.command_counter[env_ids] += 1
+        self._resample_command(env_ids)
 
     @abstractmethod
     def _update_metrics(self):
@@ -81,10 +101,8 @@ class CommandManager(ManagerBase):
             self.cfg.debug_vis = False if not hasattr(self.cfg, "debug_vis") else self.cfg.debug_vis
 
     def __str__(self) -> str:
-        msg = f"<CommandManager> contains {len(self._terms.values())} active terms.\n"
-        for index, (name, term) in enumerate(self._terms.items()):
-            msg += f"  {index:3d} | {name:<32s} | {term.__class__.__name__}\n"
-        return msg
+        rows = [f"  {i:3d} | {name:<32s} | {type(term).__name__}" for i, (name, term) in enumerate(self._terms.items())]
+        return "\n".join([f"<CommandManager> contains {len(self._terms)} active terms."] + rows) + "\n"
 
     @property
     def active_terms(self) -> list[str]:
@@ -102,14 +120,10 @@ class CommandManager(ManagerBase):
             term.set_debug_vis(debug_vis)
 
     def reset(self, env_ids: Sequence[int] | None = None) -> dict[str, torch.Tensor]:
-        if env_ids is None:
-            env_ids = slice(None)
-        extras = {}
-        for name, term in self._terms.items():
-            metrics = term.reset(env_ids=env_ids)
-            for metric_name, metric_value in metrics.items():
-                extras[f"Metrics/{name}/{metric_name}"] = metric_value
-        return extras
+        """``Metrics/<term>/<metric>`` of the envs that end their episode (command_manager.py:351-356)."""
+        rows = slice(None) if env_ids is None else env_ids
+        return {f"Metrics/{name}/{metric}": value
+                for name, term in self._terms.items() for metric, value in term.reset(env_ids=rows).items()}
 
     def compute(self, dt: float):
         for term in self._terms.values():

@@ -76,38 +76,49 @@ class ManagerBase(ABC):
         return cfg.items() if isinstance(cfg, dict) else cfg.__dict__.items()
 
     def _resolve_common_term_cfg(self, term_name: str, term_cfg: ManagerTermBaseCfg, min_argc: int = 1):
+        """What every manager does to a term cfg before it uses it (contract: ``LAB/managers/manager_base.py:219-298``;
+        the exception TYPES are the reference's, see SURVEY.md 8b "Errors"): bind scene entities, turn ``func`` into a
+        callable (``"module:attr"`` strings, class terms instantiated with ``cfg=`` / ``env=``) and make sure ``params``
+        names exactly the arguments ``func`` takes after the ``min_argc`` the manager supplies itself."""
         if not isinstance(term_cfg, ManagerTermBaseCfg):
-            raise TypeError(
-                f"Configuration for the term '{term_name}' is not of type ManagerTermBaseCfg."
-                f" Received: '{type(term_cfg)}'."
-            )
+            raise TypeError(f"term '{term_name}': expected a ManagerTermBaseCfg, got {type(term_cfg)!r}")
+        self._bind_scene_entities(term_name, term_cfg)
+        term_cfg.func = self._as_callable(term_name, term_cfg)
+        self._check_params(term_name, term_cfg, min_argc)
+
+    def _bind_scene_entities(self, term_name: str, term_cfg: ManagerTermBaseCfg) -> None:
         for key, value in term_cfg.params.items():
-            if isinstance(value, SceneEntityCfg):
-                try:
-                    value.resolve(self._env.scene)
-                except ValueError as e:
-                    raise ValueError(f"Error while parsing '{term_name}:{key}'. {e}")
-            term_cfg.params[key] = value
-        if isinstance(term_cfg.func, str):
-            term_cfg.func = string_to_callable(term_cfg.func)
-        if inspect.isclass(term_cfg.func):
-            if not issubclass(term_cfg.func, ManagerTermBase):
-                raise TypeError(
-                    f"Configuration for the term '{term_name}' is not of type ManagerTermBase."
-                    f" Received: '{type(term_cfg.func)}'."
-                )
-            term_cfg.func = term_cfg.func(cfg=term_cfg, env=self._env)
-        if not callable(term_cfg.func):
-            raise AttributeError(f"The term '{term_name}' is not callable. Received: {term_cfg.func}")
-        # params must cover exactly the non-default arguments after the first `min_argc`
-        term_params = list(term_cfg.params.keys())
+            if not isinstance(value, SceneEntityCfg):
+                continue
+            try:
+                value.resolve(self._env.scene)        # names -> joint_ids / body_ids (scene_entity_cfg.py:112-177)
+            except ValueError as err:
+                raise ValueError(f"term '{term_name}', parameter '{key}': {err}") from err
+
+    def _as_callable(self, term_name: str, term_cfg: ManagerTermBaseCfg):
+        func = term_cfg.func
+        if isinstance(func, str):
+            func = string_to_callable(func)
+        if inspect.isclass(func):
+            if not issubclass(func, ManagerTermBase):
+                raise TypeError(f"term '{term_name}': a class term must derive from ManagerTermBase, got {func!r}")
+            func = func(cfg=term_cfg, env=self._env)
+        if not callable(func):
+            raise AttributeError(f"term '{term_name}': {func!r} cannot be called")
+        return func
+
+    @staticmethod
+    def _check_params(term_name: str, term_cfg: ManagerTermBaseCfg, min_argc: int) -> None:
         sig = inspect.signature(term_cfg.func).parameters
-        with_defaults = [a for a in sig if sig[a].default is not inspect.Parameter.empty]
-        without_defaults = [a for a in sig if sig[a].default is inspect.Parameter.empty]
-        args = without_defaults + with_defaults
-        if len(args) > min_argc:
-            if set(args[min_argc:]) != set(term_params + with_defaults):
-                raise ValueError(
-                    f"The term '{term_name}' expects mandatory parameters: {without_defaults[min_argc:]}"
-                    f" and optional parameters: {with_defaults}, but received: {term_params}."
-                )
+        required = [name for name, p in sig.items() if p.default is inspect.Parameter.empty]
+        optional = [name for name, p in sig.items() if p.default is not inspect.Parameter.empty]
+        # positional slots the manager fills (env, and env_ids for event / curriculum terms) come first
+        from_cfg = (required + optional)[min_argc:]
+        if not from_cfg:
+            return
+        given = set(term_cfg.params)
+        if set(from_cfg) != given | set(optional):
+            raise ValueError(
+                f"term '{term_name}': params {sorted(given)} do not fit the signature -- required beyond the first"
+                f" {min_argc}: {required[min_argc:]}, optional: {optional}"
+            )

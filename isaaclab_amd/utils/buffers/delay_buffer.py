@@ -1,4 +1,14 @@
-"""Per-env delayed read of a command stream (``LAB/utils/buffers/delay_buffer.py:15-177``)."""
+"""Per-env delayed read of a stream of tensors -- the interface of ``LAB/utils/buffers/delay_buffer.py:15-177`` over a
+device-resident design.
+
+A :class:`CircularBuffer` of ``history_length + 1`` slots holds the stream; ``compute(data)`` pushes one sample and
+returns, for every env, the sample pushed ``time_lags[env]`` calls ago (one launch: ``append_and_read``).  The lags live
+on the device and so does their range check: ``set_time_lag`` with a tensor records "some lag left [0, history_length]"
+in a device flag and stores the lags clamped into the ring, so nothing on the step path waits for the host (the
+reference reads ``min`` / ``max`` back with two ``.item()`` calls on every reset of a DelayedPDActuator).  The
+``ValueError`` the reference raises is raised by the next host-visible look at the lags: ``min_time_lag`` /
+``max_time_lag`` / ``validate()``.  Integer arguments are checked on the host at once (no device work needed).
+"""
 from __future__ import annotations
 
 from collections.abc import Sequence
@@ -10,59 +20,63 @@ from .circular_buffer import CircularBuffer
 
 class DelayBuffer:
     def __init__(self, history_length: int, batch_size: int, device: str):
-        self._history_length = max(0, history_length)
-        self._circular_buffer = CircularBuffer(self._history_length + 1, batch_size, device)
-        self._min_time_lag = 0
-        self._max_time_lag = 0
-        self._time_lags = torch.zeros(batch_size, dtype=torch.int, device=device)
+        self._history_length = max(0, int(history_length))
+        self._ring = CircularBuffer(self._history_length + 1, batch_size, device)
+        self._lags = torch.zeros(batch_size, dtype=torch.int32, device=device)
+        # int32 {smallest requested lag, largest requested lag} of the tensor calls so far (device-side range check)
+        self._requested = torch.zeros(2, dtype=torch.int32, device=device)
 
-    @property
-    def batch_size(self) -> int:
-        return self._circular_buffer.batch_size
-
-    @property
-    def device(self) -> str:
-        return self._circular_buffer.device
-
-    @property
-    def history_length(self) -> int:
-        return self._history_length
+    # -- read-only views -----------------------------------------------------------------------------
+    batch_size = property(lambda self: self._ring.batch_size)
+    device = property(lambda self: self._ring.device)
+    history_length = property(lambda self: self._history_length)
+    time_lags = property(lambda self: self._lags)
 
     @property
     def min_time_lag(self) -> int:
-        return self._min_time_lag
+        """Smallest lag in use (reads the device: one synchronisation, not on the step path)."""
+        self.validate()
+        return int(self._lags.min())
 
     @property
     def max_time_lag(self) -> int:
-        return self._max_time_lag
+        self.validate()
+        return int(self._lags.max())
 
-    @property
-    def time_lags(self) -> torch.Tensor:
-        return self._time_lags
+    def validate(self) -> None:
+        """Raises the reference's errors (delay_buffer.py:141-149) if a tensor handed to ``set_time_lag`` held a lag
+        outside ``[0, history_length]``.  Host round trip; call it where a synchronisation is acceptable."""
+        lo, hi = (int(v) for v in self._requested.tolist())
+        if lo < 0:
+            raise ValueError(f"The minimum time lag cannot be negative. Received: {lo}")
+        if hi > self._history_length:
+            raise ValueError(f"The maximum time lag cannot be larger than the history length. Received: {hi}")
 
+    # -- configuration -------------------------------------------------------------------------------
     def set_time_lag(self, time_lag: int | torch.Tensor, batch_ids: Sequence[int] | None = None):
-        if batch_ids is None:
-            batch_ids = slice(None)
-        if isinstance(time_lag, int):
-            self._time_lags[batch_ids] = time_lag
-        elif isinstance(time_lag, torch.Tensor):
-            if time_lag.dtype not in [torch.int, torch.long]:
-                raise TypeError(f"Invalid dtype for time_lag: {time_lag.dtype}. Expected torch.int or torch.long.")
-            self._time_lags[batch_ids] = time_lag.to(device=self.device, dtype=torch.int)
-        else:
+        rows = slice(None) if batch_ids is None else batch_ids
+        if isinstance(time_lag, bool) or not isinstance(time_lag, (int, torch.Tensor)):
             raise TypeError(f"Invalid type for time_lag: {type(time_lag)}. Expected int or integer tensor.")
-        # reset-time validation, same host round trip as the reference (delay_buffer.py:141-149)
-        self._min_time_lag = int(torch.min(self._time_lags).item())
-        self._max_time_lag = int(torch.max(self._time_lags).item())
-        if self._min_time_lag < 0:
-            raise ValueError(f"The minimum time lag cannot be negative. Received: {self._min_time_lag}")
-        if self._max_time_lag > self._history_length:
-            raise ValueError(
-                f"The maximum time lag cannot be larger than the history length. Received: {self._max_time_lag}"
-            )
+        if isinstance(time_lag, int):
+            if time_lag < 0:
+                raise ValueError(f"The minimum time lag cannot be negative. Received: {time_lag}")
+            if time_lag > self._history_length:
+                raise ValueError(f"The maximum time lag cannot be larger than the history length. Received: {time_lag}")
+            self._lags[rows] = time_lag
+            return
+        if time_lag.dtype not in (torch.int32, torch.int64):
+            raise TypeError(f"Invalid dtype for time_lag: {time_lag.dtype}. Expected torch.int or torch.long.")
+        lag = time_lag.to(device=self.device, dtype=torch.int32)
+        if lag.numel() > 0:
+            # range check without leaving the device: widen the recorded {min, max} of everything requested so far
+            torch.minimum(self._requested[0], lag.min(), out=self._requested[0])
+            torch.maximum(self._requested[1], lag.max(), out=self._requested[1])
+        self._lags[rows] = lag.clamp(0, self._history_length)
 
     def reset(self, batch_ids: Sequence[int] | None = None):
-        self._circular_buffer.reset(batch_ids)
+        self._ring.reset(batch_ids)
 
+    # -- the step --------------------------------------------------------------------------------------
     def compute(self, data: torch.Tensor) -> torch.Tensor:
-        return self._circular_buffer.append_and_read(data, self._time_lags)
+        """Push ``data`` (batch_size, ...) and return the delayed samples (same shape)."""
+        return self._ring.append_and_read(data, self._lags)

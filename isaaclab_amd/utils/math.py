@@ -308,25 +308,41 @@ def transform_points(points: torch.Tensor, pos: torch.Tensor | None = None, quat
 # device in stream order, so a call captured in a hipGraph keeps drawing fresh numbers.
 _SAMPLE_KINDS = L._parse_enum(L._HDR, "MDP_SAMPLE_")
 _sampler_state: dict[int, torch.Tensor] = {}
+_sampler_seed: dict[int, int | None] = {}      # torch.initial_seed() the state was derived from (None: seed_samplers)
 
 
 def seed_samplers(seed: int, device="cuda:0") -> None:
+    """Explicit seed of the device generator of ``device`` (stays until the next call of this function)."""
     dev = torch.device(device)
-    _sampler_state[L.device_index(dev)] = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+    idx = L.device_index(dev)
+    _sampler_state[idx] = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+    _sampler_seed[idx] = None
 
 
 def _state(device) -> torch.Tensor:
     dev = torch.device(device)
     if dev.type != "cuda":
+        # no torch / CPU arithmetic anywhere in this package's product path (DESIGN.md section 0): the reference's CPU
+        # call sites of these samplers (physics-property randomisation at start-up, events.py:115, 999-1003) are
+        # out of scope; a CPU tensor here is a caller's mistake, not something to paper over with a second code path
         raise ValueError(f"samplers run on the HIP device generator; got device '{device}' (there is no CPU path)")
     idx = L.device_index(dev)
-    if idx not in _sampler_state:
-        seed_samplers(torch.initial_seed(), dev)
+    # like the reference's draws, these follow torch's global seed: torch.manual_seed() / env.seed() after the first draw
+    # starts a new stream (the state is rebuilt when torch.initial_seed() no longer is the seed it was derived from)
+    seed_now = torch.initial_seed()
+    if idx not in _sampler_state or (_sampler_seed.get(idx) is not None and _sampler_seed[idx] != seed_now):
+        _sampler_state[idx] = torch.tensor([int(seed_now) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+        _sampler_seed[idx] = seed_now
     return _sampler_state[idx]
 
 
 def _sample(kind: str, shape: tuple, device, a=None, b=None, scalars=(0.0, 0.0, 0.0), width: int = 1,
             _inject: torch.Tensor | None = None) -> torch.Tensor:
+    # tensor bounds broadcast against ``size`` by torch's rules, as in the reference's ``rand(*size) * (upper - lower) +
+    # lower``: the result has the broadcast shape
+    for t in (a, b):
+        if t is not None:
+            shape = tuple(torch.broadcast_shapes(tuple(shape), tuple(t.shape)))
     n = 1
     for d_ in shape:
         n *= int(d_)

@@ -95,3 +95,24 @@ def to_dev(x, device):
 
 def to_np(t):
     return t.detach().cpu().numpy()
+
+
+# Observation floors (the contract is <= 1e-5 RELATIVE; a floor is only needed where a term cancels towards zero):
+#  * every column but the height scan: 4e-6 absolute -- two ulps of the O(10) operands (joint positions, velocities,
+#    commands) a column is the difference or rotation of;
+#  * height-scan columns (the last 187): (sensor z - hit z) - 0.5 with the hit z taken from a ray that starts 20 m above the
+#    sensor, t = 20 +- 1 and its last bit is 1.9e-6: the measured worst case is four of them, 7.6e-6
+#    (profiles/r02_parity_error_table.txt, tools/soak_env_step.py), i.e. 4e-7 relative to the operand the error comes
+#    from; the floor is 1e-5 absolute = 5e-7 of that operand.
+OBS_ATOL = 4.0e-6
+SCAN_ATOL = 1.0e-5
+
+
+def assert_obs_close(got, exp, scan_cols: int = 0, msg: str = ""):
+    """Policy observation (N, O) against the oracle's: rtol 1e-5 everywhere, per-column-family absolute floors."""
+    got, exp = np.asarray(got), np.asarray(exp)
+    assert got.shape == exp.shape, f"{msg}: shape {got.shape} vs {exp.shape}"
+    split = got.shape[1] - scan_cols
+    assert_close(got[:, :split], exp[:, :split], rtol=RTOL, atol=OBS_ATOL, msg=msg + " (non-scan columns)")
+    if scan_cols:
+        assert_close(got[:, split:], exp[:, split:], rtol=RTOL, atol=SCAN_ATOL, msg=msg + " (height-scan columns)")

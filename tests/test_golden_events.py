@@ -174,10 +174,19 @@ def test_gpu_scaler_against_reference_vectors(device):
     from isaaclab_amd.rl import RunningStandardScaler
 
     sc = RunningStandardScaler(G["scaler_x"].shape[2], device=device)
+    # two references: (1) the vectors the reference class produced -- it takes torch.mean / torch.var of the fp32 batch in
+    # fp32, so they carry ITS reduction error (1.2e-4 relative) and only pin the statements; (2) the same statements
+    # evaluated in fp64 (the oracle), which is what the contract's 1e-5 is measured against
+    orc = RunningStandardScalerNP(G["scaler_x"].shape[2])
     for k in range(G["scaler_x"].shape[0]):
         y = sc(_dev(G["scaler_x"][k], device), train=True)
         assert_close(to_np(y), G["scaler_y"][k], rtol=1e-4, atol=2e-5, msg=f"batch {k}")   # reference reduces in fp32
-    assert_close(to_np(sc(_dev(G["scaler_x"][:2], device), train=True)), G["scaler_y3"], rtol=1e-4, atol=2e-5)
+        assert_close(to_np(y), orc.compute(G["scaler_x"][k], train=True), rtol=1e-5, atol=2e-6, msg=f"batch {k} vs fp64")
+        np.testing.assert_allclose(to_np(sc.running_mean), orc.running_mean, rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(to_np(sc.running_variance), orc.running_variance, rtol=1e-11)
+    y3 = sc(_dev(G["scaler_x"][:2], device), train=True)
+    assert_close(to_np(y3), G["scaler_y3"], rtol=1e-4, atol=2e-5)
+    assert_close(to_np(y3), orc.compute(G["scaler_x"][:2], train=True), rtol=1e-5, atol=2e-6, msg="3-d batch vs fp64")
     np.testing.assert_allclose(to_np(sc.running_mean), G["scaler_mean"], rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(to_np(sc.running_variance), G["scaler_var"], rtol=1e-4)
     assert float(sc.current_count) == G["scaler_count"][0]

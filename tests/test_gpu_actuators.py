@@ -141,8 +141,8 @@ def test_actuator_net_lstm(golden, device, tag):
         a.compute(_action(io, device, ("q_des", "_", "_")), to_dev(io["q"], device), to_dev(io["qd"], device))
         if t == 1:
             a.reset([2, 5])
-        assert_close(to_np(a.computed_effort), G[f"{tag}_computed"][t], rtol=1e-5, atol=1e-5, msg=f"{tag} t={t}")
-        assert_close(to_np(a.applied_effort), G[f"{tag}_applied"][t], rtol=1e-5, atol=1e-5, msg=f"{tag} t={t}")
+        assert_close(to_np(a.computed_effort), G[f"{tag}_computed"][t], rtol=1e-5, atol=4e-6, msg=f"{tag} t={t}")
+        assert_close(to_np(a.applied_effort), G[f"{tag}_applied"][t], rtol=1e-5, atol=4e-6, msg=f"{tag} t={t}")
         assert_close(to_np(a.sea_hidden_state), G[f"{tag}_h"][t], rtol=1e-5, atol=2e-6, msg=f"{tag} h t={t}")
         assert_close(to_np(a.sea_cell_state), G[f"{tag}_c"][t], rtol=1e-5, atol=2e-6, msg=f"{tag} c t={t}")
 
@@ -166,8 +166,8 @@ def test_actuator_net_mlp(golden, device, order):
     for t in range(seq.shape[0]):
         io = dict(zip(("q_des", "q", "qd"), seq[t]))
         a.compute(_action(io, device, ("q_des", "_", "_")), to_dev(io["q"], device), to_dev(io["qd"], device))
-        assert_close(to_np(a.computed_effort), G[f"mlp_{order}_computed"][t], rtol=1e-5, atol=1e-5, msg=f"t={t}")
-        assert_close(to_np(a.applied_effort), G[f"mlp_{order}_applied"][t], rtol=1e-5, atol=1e-5, msg=f"t={t}")
+        assert_close(to_np(a.computed_effort), G[f"mlp_{order}_computed"][t], rtol=1e-5, atol=4e-6, msg=f"t={t}")
+        assert_close(to_np(a.applied_effort), G[f"mlp_{order}_applied"][t], rtol=1e-5, atol=4e-6, msg=f"t={t}")
         if t == 2:
             a.reset([0, 3])
 
@@ -192,8 +192,8 @@ def test_actuator_net_lstm_full_size_vs_oracle(golden, device):
         qd = (rng.standard_normal((n, j)) * 4).astype(np.float32)
         comp, app, h, c = A.actuator_net_lstm(q_des, q, qd, h, c, lstm, dec, np.float32(80.0), np.float32(7.5), 120.0)
         a.compute(_action({"q_des": q_des}, device, ("q_des", "_", "_")), to_dev(q, device), to_dev(qd, device))
-        assert_close(to_np(a.computed_effort), comp, rtol=1e-5, atol=2e-5, msg=f"t={t}")
-        assert_close(to_np(a.applied_effort), app, rtol=1e-5, atol=2e-5, msg=f"t={t}")
+        assert_close(to_np(a.computed_effort), comp, rtol=1e-5, atol=4e-6, msg=f"t={t}")
+        assert_close(to_np(a.applied_effort), app, rtol=1e-5, atol=4e-6, msg=f"t={t}")
         assert_close(to_np(a.sea_hidden_state), h, rtol=1e-5, atol=4e-6)
 
 

@@ -6,7 +6,7 @@ lie on or below the ray start, repeated casts are idempotent, episode sums equal
 import numpy as np
 import pytest
 
-from conftest import assert_close, to_np
+from conftest import assert_close, assert_obs_close, to_np
 
 pytestmark = pytest.mark.gpu
 
@@ -45,7 +45,7 @@ def slice_recording(rec, ids):
 
 @pytest.mark.parametrize("name,n,fast", (("anymal_d_rough", 4096, False), ("anymal_c_rough", 16384, False),
                                          ("anymal_c_rough", 4096, True), ("anymal_d_rough", 16384, True),
-                                         ("h1_rough", 8192, False)))
+                                         ("h1_rough", 8192, False), ("anymal_d_flat", 4096, True)))
 def test_full_size_slice_vs_oracle_and_properties(device, name, n, fast):
     """configs[1] (Rough Anymal-D, 4096 envs, 765,952 rays per cast), configs[2] (Anymal-C LSTM, 16384 envs) and the
     per-GPU share of configs[3] (H1, three implicit actuator groups).  ``fast``: grid-accelerated mesh + persistent
@@ -76,11 +76,16 @@ def test_full_size_slice_vs_oracle_and_properties(device, name, n, fast):
         np.testing.assert_array_equal(got[2], ref[t][2])
         np.testing.assert_array_equal(got[3], ref[t][3])
         assert_close(got[1], ref[t][1], rtol=1e-5, atol=2e-6, msg=f"reward step {t}")
-        assert_close(got[0], ref[t][0], rtol=1e-5, atol=1e-5, msg=f"obs step {t}")
+        assert_obs_close(got[0], ref[t][0], scan_cols=187 if got[0].shape[1] > 187 else 0, msg=f"obs step {t}")
     # (b) properties over all envs
     rm = env.reward_manager
     total = torch.stack([rm._episode_sums[k] for k in rm.active_terms]).sum(0)
     assert_close(to_np(total), to_np(rewards), rtol=1e-4, atol=1e-5)
+    if "height_scanner" not in env.scene.sensors:
+        # configs[0] at its real size: the flat task's post-physics launch is manager blocks only, 12 waves x 16 envs
+        # (256 blocks at 4096 envs) -- the slice above is its parity check, there is no cast to look at
+        assert outs[0][0].shape == (n, 48) and np.isfinite(outs[-1][0]).all()
+        return
     hs = env.scene["height_scanner"]
     hits = to_np(hs.data.ray_hits_w)
     assert hits.shape == (n, 187, 3) and np.isfinite(hits).all()
@@ -145,4 +150,4 @@ def test_full_size_resets_inside_the_post_physics_launch(device):
         np.testing.assert_array_equal(got[2], ref[t][2])
         np.testing.assert_array_equal(got[3], ref[t][3])
         assert_close(got[1], ref[t][1], rtol=1e-5, atol=2e-6, msg=f"reward step {t}")
-        assert_close(got[0], ref[t][0], rtol=1e-5, atol=1e-5, msg=f"obs step {t}")
+        assert_obs_close(got[0], ref[t][0], scan_cols=187 if got[0].shape[1] > 187 else 0, msg=f"obs step {t}")

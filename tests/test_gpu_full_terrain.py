@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import to_dev, to_np
+from conftest import assert_obs_close, to_dev, to_np
 from oracle import raycast_np as RC
 
 pytestmark = pytest.mark.gpu
@@ -194,7 +194,7 @@ def test_full_terrain_env_step_slice_vs_oracle(device, full_terrain):
         np.testing.assert_array_equal(got[2], ref[t][2])
         np.testing.assert_array_equal(got[3], ref[t][3])
         np.testing.assert_allclose(got[1], ref[t][1], rtol=1e-5, atol=2e-6, err_msg=f"reward step {t}")
-        np.testing.assert_allclose(got[0], ref[t][0], rtol=1e-5, atol=1e-5, err_msg=f"obs step {t}")
+        assert_obs_close(got[0], ref[t][0], scan_cols=187, msg=f"obs step {t}")
     # the hit buffer of the last cast, all envs of the slice, bit for bit
     hs = env.scene["height_scanner"]
     pos, quat = to_np(hs.data.pos_w), to_np(hs.data.quat_w)

@@ -103,6 +103,25 @@ def test_gpu_samplers_generator(device):
     assert np.abs(rq.mean(0)).max() < 0.01 and np.abs((rq ** 2).mean(0) - 0.25).max() < 0.01
     with pytest.raises(ValueError, match="no CPU path"):
         M.sample_uniform(0.0, 1.0, 4, "cpu")
+    # the draws follow torch's global seed like the reference's: manual_seed() after the first draw starts a new stream,
+    # the same seed gives the same stream again; seed_samplers() pins a seed of its own
+    import torch
+
+    M._sampler_state.clear(); M._sampler_seed.clear()
+    torch.manual_seed(123)
+    a = to_np(M.sample_uniform(0.0, 1.0, 64, dev))
+    torch.manual_seed(456)
+    b = to_np(M.sample_uniform(0.0, 1.0, 64, dev))
+    torch.manual_seed(123)
+    c = to_np(M.sample_uniform(0.0, 1.0, 64, dev))
+    assert np.array_equal(a, c) and not np.array_equal(a, b)
+    # tensor bounds broadcast against `size` like `rand(*size) * (upper - lower) + lower`
+    lo = torch.tensor([[0.0], [10.0], [20.0]], device=dev)
+    x = to_np(M.sample_uniform(lo, lo + 1.0, (3, 5), dev))
+    assert x.shape == (3, 5) and ((x >= to_np(lo)) & (x <= to_np(lo) + 1.0)).all()
+    y = to_np(M.sample_uniform(torch.zeros(5, device=dev), torch.ones(5, device=dev), (3, 1), dev))
+    assert y.shape == (3, 5)
+    M.seed_samplers(1, dev)
 
 
 @pytest.mark.gpu
