@@ -1554,6 +1554,11 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         }
         a.cast_epb = cast->num_rays >= threads ? 1 : std::min(threads / cast->num_rays, (int)RCU_MAX_EPB);
         a.cast_slot_w = cast->num_rays >= threads ? threads : cast->num_rays;
+        static const int slot_w_env = [] { const char* v = std::getenv("MDP_POST_CAST_SLOT_W"); return v ? std::atoi(v) : 0; }();
+        if (slot_w_env > 0 && slot_w_env <= threads) {      // threads per env: an env's rays are looped over by its slot
+            a.cast_slot_w = slot_w_env;
+            a.cast_epb = std::min(threads / slot_w_env, (int)RCU_MAX_EPB);
+        }
         static const int64_t cast_cap = [] {
             const char* v = std::getenv("MDP_POST_CAST_BLOCKS");   // > 0: at most this many cast blocks, each strides over its envs
             int64_t c = v ? std::atoll(v) : 0;

@@ -45,6 +45,11 @@ typedef struct {
     // A ray reads ONE contiguous run per visited cell instead of chasing cell_tris -> tri_verts, and a
     // downward ray stops at the first record that lies entirely below its current best hit.
     const float* cell_recs;
+    // the same two arrays for EXACTLY vertical rays (mdp_rc_grid_down_exact): lists without the triangles that project
+    // to an axis-parallel segment, which such a ray can never hit (raycast.hip: is_wall); equal to cell_start /
+    // cell_recs when the mesh has none
+    const int32_t* cell_start_down;
+    const float* cell_recs_down;
     int32_t finite;  // every vertex coordinate is finite (device builder; lets vertical rays drop their zero products)
     // optional lattice patches (device builder; vertical rays only): runs of faces that form a regular height-field
     // lattice (two triangles per lattice square, LAB/terrains/height_field/utils.py:79-173) are also stored as their
@@ -568,7 +573,7 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
     mdp_hit_t best; best.t = max_t; best.face = -1;
     int32_t c;
     if (!mdp_rc_down_cell(m, ox, oy, &c)) return best;
-    const int2 cref = reinterpret_cast<const int2*>(m->cell_start)[c];   // one aligned 8-byte load
+    const int2 cref = reinterpret_cast<const int2*>(m->cell_start_down)[c];   // one aligned 8-byte load
     const int32_t braw = cref.x;
     const bool disjoint = braw < 0;
     int32_t b = MDP_RC_CELL_OFFSET(braw), e = b + cref.y;
@@ -584,7 +589,7 @@ __device__ __forceinline__ mdp_hit_t mdp_rc_grid_down_exact(const mdp_mesh_view_
         for (int i = 0; i < BATCH; ++i) {
             if (i >= n) continue;
             int32_t kk = k + i < e ? k + i : e - 1;
-            R[i] = mdp_rc_load_rec(m->cell_recs + MDP_RC_REC_STRIDE * (int64_t)kk);
+            R[i] = mdp_rc_load_rec(m->cell_recs_down + MDP_RC_REC_STRIDE * (int64_t)kk);
         }
 #pragma unroll
         for (int i = 0; i < BATCH; ++i) {
