@@ -1162,6 +1162,22 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAV
         // past the end repeat the last one's requests and store nothing)
         constexpr int OBS_U = 4;
         const int total = ne * a.n_opcols;
+        // (2) body-frame vector terms, one thread per (env, term): their root-state rows are requested HERE, in front of
+        // the operand columns' round trip, and rotated behind it -- the phase is one memory round trip, not two
+        const int nvec = ne * a.n_vterms;
+        const bool has_vec = (int)threadIdx.x < nvec;
+        Q4 vq{1.0f, 0.0f, 0.0f, 0.0f};
+        V3 vv{0.0f, 0.0f, 0.0f};
+        int v_ti = 0, v_ee = 0;
+        if (has_vec) {
+            const int le = (int)threadIdx.x / a.n_vterms;
+            v_ti = vterms[(int)threadIdx.x - le * a.n_vterms];
+            v_ee = e0 + le;
+            const mdp_term_t& t = oterms[v_ti];
+            const float* r = (const float*)t.p0 + (int64_t)v_ee * t.i0;
+            vq = ld4(r + 3);
+            vv = t.op == MDP_OBS_PROJECTED_GRAVITY ? V3{t.f0, t.f1, t.f2} : ld3(r + (t.op == MDP_OBS_BASE_LIN_VEL ? 7 : 10));
+        }
         for (int i0 = threadIdx.x; i0 < total; i0 += OBS_U * blockDim.x) {
             float va[OBS_U], vb[OBS_U], vc[OBS_U];
             int ees[OBS_U], cs[OBS_U];
@@ -1185,8 +1201,14 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAV
                 emit(t, ti, ees[u], cs[u], cs[u] - t.out_offset, obs_operand_finish(t, va[u], vb[u], vc[u]));
             }
         }
-        // (2) body-frame vector terms: one thread per (env, term) rotates once and writes the term's three columns
-        for (int i = threadIdx.x; i < ne * a.n_vterms; i += blockDim.x) {
+        if (has_vec) {
+            const mdp_term_t& t = oterms[v_ti];
+            const V3 v = quat_rotate_inverse(vq, vv);
+            for (int k = 0; k < t.dim && k < 3; ++k)
+                if (t.out_offset + k < O) emit(t, v_ti, v_ee, t.out_offset + k, k, get(v, k));
+        }
+        // (more (env, term) pairs than threads: the rest one round trip at a time)
+        for (int i = threadIdx.x + blockDim.x; i < nvec; i += blockDim.x) {
             const int le = i / a.n_vterms;
             const int ti = vterms[i - le * a.n_vterms];
             const mdp_term_t& t = oterms[ti];
