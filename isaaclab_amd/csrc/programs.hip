@@ -902,6 +902,7 @@ struct PostArgs {
     const int16_t* olists; int n_opcols, n_vterms;   // operand columns, then vector terms (mdp_program::n_opcols)
     float* obs; int ld_obs; uint64_t* orng; unsigned orng_base; int ouses_rng;
     mdp_obs_normalize_t onorm;
+    int obs_waves;   // > 0: that many of a manager block's waves write the observations next to the reward phase
     // ---- reset branch (k_post_physics<.., true> only)
     const mdp_fill_t* fills; int num_fills; float max_episode_length_s; double* log_sums; float* log;
 };
@@ -922,12 +923,117 @@ struct PostArgs {
 // per-env part of the ray caster's update for every env, in front of k_post_physics when the launch has many envs
 __global__ void __launch_bounds__(256) k_cast_pose(RaycasterUpdateArgs a) { raycaster_pose_pass(a); }
 
-template <int BATCH, bool RESET>
-__global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAVES_RESET : MDP_POST_MIN_WAVES) k_post_physics(PostArgs a) {
+// ---- observations (observation_manager.py:260-335), columns fastest: contiguous row writes.  Thread otid of othreads;
+// cmd_lds: operands that lie in the command buffer are taken from s_cmd (the new command, not stored yet)
+__device__ __forceinline__ void post_observations(const PostArgs& a, const mdp_term_t* oterms, const int16_t* col2term,
+                                                  const int16_t* opcols, const int16_t* vterms, const float (*s_cmd)[64],
+                                                  const int e0, const int e1, const unsigned b, const int otid,
+                                                  const int othreads, const bool cmd_lds) {
+    if (!a.obs) return;
+    uint64_t seed = 0, epoch = 0;
+    // own counters, tagged so that a draw never repeats one made by k_obs for the same element
+    if (a.ouses_rng) { seed = a.orng[0]; epoch = a.orng[a.orng_base + b]; }
+    const int O = a.O;
+    const int ne = e1 - e0;
+    auto emit = [&](const mdp_term_t& t, int ti, int ee, int c, int k, float v) {
+        v = obs_post(t, v, ee, k, seed, epoch | (1ull << 62), 0x4f425300u + (uint32_t)ti, (uint64_t)ee * (uint64_t)O + c);
+        a.obs[(int64_t)ee * a.ld_obs + c] = v;
+        if (a.onorm.out)     // the standardised copy for the observation's consumer (mdp_obs_normalize_t)
+            a.onorm.out[(int64_t)ee * a.onorm.ld_out + c] =
+                tclamp((v - a.onorm.mean32[c]) / a.onorm.denom[c], -a.onorm.clip, a.onorm.clip);
+    };
+    // (1) operand columns, columns fastest.  A thread requests the operands of OBS_U of its items before it
+    // finishes the first: the phase costs one memory round trip per OBS_U items instead of one per item (items
+    // past the end repeat the last one's requests and store nothing)
+    constexpr int OBS_U = 4;
+    const int total = ne * a.n_opcols;
+    // (2) body-frame vector terms, one thread per (env, term): their root-state rows are requested HERE, in front of
+    // the operand columns' round trip, and rotated behind it -- the phase is one memory round trip, not two
+    const int nvec = ne * a.n_vterms;
+    const bool has_vec = otid < nvec;
+    Q4 vq{1.0f, 0.0f, 0.0f, 0.0f};
+    V3 vv{0.0f, 0.0f, 0.0f};
+    int v_ti = 0, v_ee = 0;
+    if (has_vec) {
+        const int le = otid / a.n_vterms;
+        v_ti = vterms[otid - le * a.n_vterms];
+        v_ee = e0 + le;
+        const mdp_term_t& t = oterms[v_ti];
+        const float* r = (const float*)t.p0 + (int64_t)v_ee * t.i0;
+        vq = ld4(r + 3);
+        vv = t.op == MDP_OBS_PROJECTED_GRAVITY ? V3{t.f0, t.f1, t.f2} : ld3(r + (t.op == MDP_OBS_BASE_LIN_VEL ? 7 : 10));
+    }
+    for (int i0 = otid; i0 < total; i0 += OBS_U * othreads) {
+        float va[OBS_U], vb[OBS_U], vc[OBS_U];
+        int ees[OBS_U], cs[OBS_U];
+#pragma unroll
+        for (int u = 0; u < OBS_U; ++u) {
+            int i = i0 + u * othreads;
+            if (i >= total) i = total - 1;
+            const int le = i / a.n_opcols;
+            const int c = opcols[i - le * a.n_opcols];
+            const mdp_term_t& t = oterms[col2term[c]];
+            const float *pa, *pb, *pc;
+            obs_operand_addrs(t, a.opool, e0 + le, c - t.out_offset, &pa, &pb, &pc);
+            va[u] = *pa; vb[u] = *pb; vc[u] = *pc;
+            if (cmd_lds) {          // (block-uniform) the new command waits in s_cmd until the rewards are through
+                const float* cb = a.cmd.vel_command_b + 3 * (int64_t)e0;
+                const uint64_t span = 3ull * (uint64_t)ne;
+                const uint64_t oa = (uint64_t)(pa - cb), ob = (uint64_t)(pb - cb), oc = (uint64_t)(pc - cb);
+                if (oa < span) va[u] = s_cmd[(unsigned)oa % 3u][(unsigned)oa / 3u];
+                if (ob < span) vb[u] = s_cmd[(unsigned)ob % 3u][(unsigned)ob / 3u];
+                if (oc < span) vc[u] = s_cmd[(unsigned)oc % 3u][(unsigned)oc / 3u];
+            }
+            ees[u] = e0 + le; cs[u] = c;
+        }
+#pragma unroll
+        for (int u = 0; u < OBS_U; ++u) {
+            if (i0 + u * othreads >= total) continue;
+            const int ti = col2term[cs[u]];
+            const mdp_term_t& t = oterms[ti];
+            emit(t, ti, ees[u], cs[u], cs[u] - t.out_offset, obs_operand_finish(t, va[u], vb[u], vc[u]));
+        }
+    }
+    if (has_vec) {
+        const mdp_term_t& t = oterms[v_ti];
+        const V3 v = quat_rotate_inverse(vq, vv);
+        for (int k = 0; k < t.dim && k < 3; ++k)
+            if (t.out_offset + k < O) emit(t, v_ti, v_ee, t.out_offset + k, k, get(v, k));
+    }
+    // (more (env, term) pairs than threads: the rest one round trip at a time)
+    for (int i = otid + othreads; i < nvec; i += othreads) {
+        const int le = i / a.n_vterms;
+        const int ti = vterms[i - le * a.n_vterms];
+        const mdp_term_t& t = oterms[ti];
+        const int ee = e0 + le;
+        const float* r = (const float*)t.p0 + (int64_t)ee * t.i0;
+        V3 v = t.op == MDP_OBS_PROJECTED_GRAVITY ? V3{t.f0, t.f1, t.f2} : ld3(r + (t.op == MDP_OBS_BASE_LIN_VEL ? 7 : 10));
+        v = quat_rotate_inverse(ld4(r + 3), v);
+        for (int k = 0; k < t.dim && k < 3; ++k)
+            if (t.out_offset + k < O) emit(t, ti, ee, t.out_offset + k, k, get(v, k));
+    }
+    if (a.ouses_rng && otid == 0) a.orng[a.orng_base + b] = epoch + 1;
+}
+
+// ROLES: the instantiation with wave roles in the manager blocks (a.obs_waves observation waves next to the reward
+// phase); launches with cast blocks keep the instantiation without them (three-wave blocks: nothing to split)
+// (used by launches without cast blocks, one 12-wave block per CU: a 128-register budget, no spills -- flat Anymal-D,
+// 4096 envs: post-physics launch 16.8 us at 6 waves per SIMD, 15.9 us at 4)
+#ifndef MDP_POST_MIN_WAVES_ROLES
+#define MDP_POST_MIN_WAVES_ROLES 4
+#endif
+template <int BATCH, bool RESET, bool STAGED, bool ROLES>
+__global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAVES_RESET
+                                                        : (ROLES ? MDP_POST_MIN_WAVES_ROLES : MDP_POST_MIN_WAVES))
+k_post_physics(PostArgs a) {
+    static_assert(!(RESET && ROLES), "the reset branch orders rewards -> reset -> observations");
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
         MDP_STAMP(0, 1);
-        raycaster_update_down_blocks<BATCH>(a.cast, a.cast_epb, a.cast_slot_w, blockIdx.x - a.nb_post, a.nb_cast);
+        if constexpr (STAGED)
+            raycaster_update_down_blocks_staged(a.cast, a.cast_epb, a.cast_slot_w, blockIdx.x - a.nb_post, a.nb_cast, s_dyn);
+        else
+            raycaster_update_down_blocks<BATCH>(a.cast, a.cast_epb, a.cast_slot_w, blockIdx.x - a.nb_post, a.nb_cast);
         MDP_STAMP(1);
         return;
     }
@@ -979,13 +1085,23 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAV
     if (a.len_inc && wave == 0 && e < N) a.len_inc[e] += 1;
     __threadfence_block();
     __syncthreads();
+    __shared__ float s_cmd[3][64];      // the new command of the block's envs until the rewards are through
+    auto observations = [&](const int otid, const int othreads, const bool cmd_lds) {
+        post_observations(a, oterms, col2term, opcols, vterms, s_cmd, e0, e1, b, otid, othreads, cmd_lds);
+    };
     // ---- terminations (termination_manager.py:151-174): wave w evaluates terms w, w + nwaves, ...
     // Without the reset branch the command update (command_manager.py:151-187) is evaluated HERE, by the last wave, next
     // to the termination terms -- it needs the updated root state and nothing the terminations or rewards produce --
     // and only its result, the new command, is held back in registers until the rewards have read the previous one
     // (stored where the command phase used to be).  One dependent phase less in the block's chain.
-    __shared__ float s_cmd[3][64];      // the new command of the block's envs until the rewards are through
     const bool cmd_early = !RESET && a.has_cmd;
+    // Wave roles (no reset branch): the observations need the updated scene and the new command, nothing the terminations
+    // or rewards produce, so the block's last a.obs_waves waves write them WHILE the other waves evaluate the reward terms
+    // (they read the new command from s_cmd: the command buffer itself changes only once the rewards are through).
+    // The chain update -> terminations -> rewards -> observations loses its last link.
+    const int nB = (ROLES && a.obs && a.obs_waves > 0 && a.obs_waves < nwaves) ? a.obs_waves : 0;
+    const int nA = nwaves - nB;          // waves of the termination / reward phases
+    const bool obs_wave = nB > 0 && wave >= nA;
     if (cmd_early && wave == nwaves - 1) {
         uint64_t seed = 0, epoch = 0;
         const bool gen = a.cmd.rng_state != nullptr && a.cmd.injected_u == nullptr;
@@ -1000,7 +1116,7 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAV
         }
         if (gen && lane == 0) a.cmd.rng_state[4 + b] = epoch + 1;
     }
-    for (int ti = wave; ti < a.Tt; ti += nwaves) {
+    for (int ti = obs_wave ? a.Tt : wave; ti < a.Tt; ti += nA) {
         const mdp_term_t& t = tterms[ti];
         bool v = e < N ? term_value(t, a.tpool, e) : false;
         if (a.term_dones && e < N) a.term_dones[(int64_t)t.out_offset * N + e] = v ? 1 : 0;
@@ -1022,7 +1138,7 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAV
     __syncthreads();
     MDP_STAMP(2);
     // ---- rewards (reward_manager.py:128-157)
-    for (int ti = wave; ti < a.Tr; ti += nwaves) {
+    for (int ti = obs_wave ? a.Tr : wave; ti < a.Tr; ti += nA) {
         const mdp_term_t& t = rterms[ti];
         float value = 0.0f;
         if (e < N && t.weight != 0.0f) {
@@ -1031,6 +1147,12 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAV
             if (a.step) a.step[(int64_t)e * a.Tr + t.out_offset] = value / a.step_dt;
         }
         s_val[ti * 64 + lane] = value;
+    }
+    // ---- observations (observation_manager.py:260-335) with wave roles: by the observation waves next to the reward
+    // terms (or, a.obs_waves == 0, by every wave behind its reward terms); the new command comes from s_cmd
+    if constexpr (ROLES) {
+        if (nB == 0 || obs_wave)
+            observations((int)threadIdx.x - (nB == 0 ? 0 : nA * 64), nB == 0 ? (int)blockDim.x : nB * 64, cmd_early);
     }
     __syncthreads();
     if (wave == 0 && e < N && a.Tr > 0) {
@@ -1143,84 +1265,8 @@ __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAV
         __syncthreads();
     }
     MDP_STAMP(4);
-    // ---- observations (observation_manager.py:260-335), columns fastest: contiguous row writes
-    if (a.obs) {
-        uint64_t seed = 0, epoch = 0;
-        // own counters, tagged so that a draw never repeats one made by k_obs for the same element
-        if (a.ouses_rng) { seed = a.orng[0]; epoch = a.orng[a.orng_base + b]; }
-        const int O = a.O;
-        const int ne = e1 - e0;
-        auto emit = [&](const mdp_term_t& t, int ti, int ee, int c, int k, float v) {
-            v = obs_post(t, v, ee, k, seed, epoch | (1ull << 62), 0x4f425300u + (uint32_t)ti, (uint64_t)ee * (uint64_t)O + c);
-            a.obs[(int64_t)ee * a.ld_obs + c] = v;
-            if (a.onorm.out)     // the standardised copy for the observation's consumer (mdp_obs_normalize_t)
-                a.onorm.out[(int64_t)ee * a.onorm.ld_out + c] =
-                    tclamp((v - a.onorm.mean32[c]) / a.onorm.denom[c], -a.onorm.clip, a.onorm.clip);
-        };
-        // (1) operand columns, columns fastest.  A thread requests the operands of OBS_U of its items before it
-        // finishes the first: the phase costs one memory round trip per OBS_U items instead of one per item (items
-        // past the end repeat the last one's requests and store nothing)
-        constexpr int OBS_U = 4;
-        const int total = ne * a.n_opcols;
-        // (2) body-frame vector terms, one thread per (env, term): their root-state rows are requested HERE, in front of
-        // the operand columns' round trip, and rotated behind it -- the phase is one memory round trip, not two
-        const int nvec = ne * a.n_vterms;
-        const bool has_vec = (int)threadIdx.x < nvec;
-        Q4 vq{1.0f, 0.0f, 0.0f, 0.0f};
-        V3 vv{0.0f, 0.0f, 0.0f};
-        int v_ti = 0, v_ee = 0;
-        if (has_vec) {
-            const int le = (int)threadIdx.x / a.n_vterms;
-            v_ti = vterms[(int)threadIdx.x - le * a.n_vterms];
-            v_ee = e0 + le;
-            const mdp_term_t& t = oterms[v_ti];
-            const float* r = (const float*)t.p0 + (int64_t)v_ee * t.i0;
-            vq = ld4(r + 3);
-            vv = t.op == MDP_OBS_PROJECTED_GRAVITY ? V3{t.f0, t.f1, t.f2} : ld3(r + (t.op == MDP_OBS_BASE_LIN_VEL ? 7 : 10));
-        }
-        for (int i0 = threadIdx.x; i0 < total; i0 += OBS_U * blockDim.x) {
-            float va[OBS_U], vb[OBS_U], vc[OBS_U];
-            int ees[OBS_U], cs[OBS_U];
-#pragma unroll
-            for (int u = 0; u < OBS_U; ++u) {
-                int i = i0 + u * (int)blockDim.x;
-                if (i >= total) i = total - 1;
-                const int le = i / a.n_opcols;
-                const int c = opcols[i - le * a.n_opcols];
-                const mdp_term_t& t = oterms[col2term[c]];
-                const float *pa, *pb, *pc;
-                obs_operand_addrs(t, a.opool, e0 + le, c - t.out_offset, &pa, &pb, &pc);
-                va[u] = *pa; vb[u] = *pb; vc[u] = *pc;
-                ees[u] = e0 + le; cs[u] = c;
-            }
-#pragma unroll
-            for (int u = 0; u < OBS_U; ++u) {
-                if (i0 + u * (int)blockDim.x >= total) continue;
-                const int ti = col2term[cs[u]];
-                const mdp_term_t& t = oterms[ti];
-                emit(t, ti, ees[u], cs[u], cs[u] - t.out_offset, obs_operand_finish(t, va[u], vb[u], vc[u]));
-            }
-        }
-        if (has_vec) {
-            const mdp_term_t& t = oterms[v_ti];
-            const V3 v = quat_rotate_inverse(vq, vv);
-            for (int k = 0; k < t.dim && k < 3; ++k)
-                if (t.out_offset + k < O) emit(t, v_ti, v_ee, t.out_offset + k, k, get(v, k));
-        }
-        // (more (env, term) pairs than threads: the rest one round trip at a time)
-        for (int i = threadIdx.x + blockDim.x; i < nvec; i += blockDim.x) {
-            const int le = i / a.n_vterms;
-            const int ti = vterms[i - le * a.n_vterms];
-            const mdp_term_t& t = oterms[ti];
-            const int ee = e0 + le;
-            const float* r = (const float*)t.p0 + (int64_t)ee * t.i0;
-            V3 v = t.op == MDP_OBS_PROJECTED_GRAVITY ? V3{t.f0, t.f1, t.f2} : ld3(r + (t.op == MDP_OBS_BASE_LIN_VEL ? 7 : 10));
-            v = quat_rotate_inverse(ld4(r + 3), v);
-            for (int k = 0; k < t.dim && k < 3; ++k)
-                if (t.out_offset + k < O) emit(t, ti, ee, t.out_offset + k, k, get(v, k));
-        }
-        if (a.ouses_rng && threadIdx.x == 0) a.orng[a.orng_base + b] = epoch + 1;
-    }
+    // ---- observations without wave roles: behind the (reset and the) command update, from the buffers
+    if constexpr (!ROLES) observations((int)threadIdx.x, (int)blockDim.x, false);
     MDP_STAMP(6);
     if (RESET) {
         if (s_last) {                                     // block-uniform, written before the command phase's barriers
@@ -1498,7 +1544,7 @@ MDP_STAMP_SETTER(mdp_debug_stamps_programs)
 static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, float physics_dt,
                                const mdp_termination_reward_args_t* tr, const mdp_velocity_command_args_t* command,
                                const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
-                               const mdp_post_reset_args_t* reset, void* stream) {
+                               const mdp_post_reset_args_t* reset, void* stream, bool clear_ticket = false) {
     MDP_REQUIRE(num_envs >= 0, "negative num_envs");
     MDP_REQUIRE(tr && tr->termination && tr->reward, "termination / reward programs required");
     mdp_program_t* tp = tr->termination;
@@ -1561,6 +1607,11 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
             const char* v = std::getenv("MDP_CAST_POSE_MIN_ENVS");
             return v ? std::atoi(v) : 8192;
         }();
+        // (read at every call, i.e. at capture time under a hipGraph: tests flip it inside one process)
+        const char* stage_v = std::getenv("MDP_RC_STAGE");
+        const int stage_env = stage_v ? std::atoi(stage_v) : 0;
+        // (the reset-carrying instantiation and meshes with non-finite vertices keep the per-ray walk)
+        ra.stage = (stage_env != 0 && !reset && cast->mesh->view.finite) ? 1 : 0;
         ra.pose_ws = cast->pose_ws;
         ra.pose_ready = (cast->pose_ws != nullptr && pose_min_envs >= 0 && num_envs >= pose_min_envs) ? 1 : 0;
         if (cast->scan && cast->scan->obs) {
@@ -1574,12 +1625,13 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
             ra.scan = *sc;
             if (!generated) ra.scan.rng = nullptr;
         }
-        a.cast_epb = cast->num_rays >= threads ? 1 : std::min(threads / cast->num_rays, (int)RCU_MAX_EPB);
+        const int max_epb = ra.stage ? (int)RCU_MAX_EPB_STAGED : (int)RCU_MAX_EPB;
+        a.cast_epb = cast->num_rays >= threads ? 1 : std::min(threads / cast->num_rays, max_epb);
         a.cast_slot_w = cast->num_rays >= threads ? threads : cast->num_rays;
         static const int slot_w_env = [] { const char* v = std::getenv("MDP_POST_CAST_SLOT_W"); return v ? std::atoi(v) : 0; }();
         if (slot_w_env > 0 && slot_w_env <= threads) {      // threads per env: an env's rays are looped over by its slot
             a.cast_slot_w = slot_w_env;
-            a.cast_epb = std::min(threads / slot_w_env, (int)RCU_MAX_EPB);
+            a.cast_epb = std::min(threads / slot_w_env, max_epb);
         }
         static const int64_t cast_cap = [] {
             const char* v = std::getenv("MDP_POST_CAST_BLOCKS");   // > 0: at most this many cast blocks, each strides over its envs
@@ -1637,10 +1689,24 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
     }
     if (reset && reset->num_fills > 0) lds += (size_t)reset->num_fills * sizeof(mdp_fill_t) + 8;
     if (lds > 60 * 1024) return fail(MDP_ERR_UNSUPPORTED, "programs too large for the LDS staging area (%zu B)", lds);
+    // the cast blocks' record table lives in the same dynamic segment (a block has one role)
+    if (cast && a.cast.stage && lds < rc_stage_lds_bytes()) lds = rc_stage_lds_bytes();
+    // waves of a manager block that write the observations next to the reward phase (0: every wave does every phase)
+    const char* obs_waves_v = std::getenv("MDP_POST_OBS_WAVES");      // read at every call, like MDP_RC_STAGE
+    const int obs_waves_env = obs_waves_v ? std::atoi(obs_waves_v) : -1;
+    // default: half the waves of the wide blocks of a launch without cast blocks (flat Anymal-D, 4096 envs, 12 waves:
+    // 46.0 us/step without roles, 44.9 / 43.7 / 44.0 with 4 / 6 / 8 observation waves); three-wave blocks keep one role
+    // -- and so do launches with more manager blocks than CUs: the roles' instantiation holds one wide block per CU (flat
+    // Anymal-D at 16,384 envs, 512 blocks: 78.3 us/step without roles, 91.3 with)
+    const int64_t nb_manager = ((int64_t)num_envs + post_envs - 1) / post_envs;
+    a.obs_waves = obs_waves_env >= 0 ? obs_waves_env : ((!cast && threads >= 512 && nb_manager <= 256) ? threads / 128 : 0);
+    if (a.obs_waves >= threads / 64 || reset || (cast && a.cast.stage)) a.obs_waves = 0;
     a.post_envs = post_envs;
     a.nb_post = (unsigned)(((int64_t)num_envs + post_envs - 1) / post_envs);
     if (cast && a.cast.pose_ready) MDP_REQUIRE(((uintptr_t)a.cast.pose_ws & 15) == 0, "cast: pose_ws must be 16-byte aligned");
     // every argument check is behind us: the pass in front of the kernel may write the sensor's buffers now
+    const bool staged = cast && a.cast.stage;
+    const dim3 grid(a.nb_post + a.nb_cast);
     auto pose_pass = [&]() {
         if (cast && a.cast.pose_ready)
             hipLaunchKernelGGL(k_cast_pose, dim3(grid_for(num_envs, 256, 1 << 20)), dim3(256), 0, as_stream(stream), a.cast);
@@ -1655,11 +1721,16 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         MDP_REQUIRE(post_envs >= 8, "reset: the log_sums workspace is sized for blocks of >= 8 envs (MDP_POST_ENVS=%d)", post_envs);
         a.fills = reset->fills; a.num_fills = reset->num_fills; a.log = reset->log;
         a.log_sums = reset->log_sums; a.max_episode_length_s = reset->max_episode_length_s;
+        // (noalloc entry point) the shared scratch array keeps the last call's contents: the block ticket starts at zero.
+        // Enqueued here, behind every argument check, so a rejected call leaves nothing in the stream / a capture
+        if (clear_ticket) MDP_CHECK_HIP(hipMemsetAsync(a.log_sums, 0, sizeof(double), as_stream(stream)));
         pose_pass();
-        hipLaunchKernelGGL((k_post_physics<1, true>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
+        hipLaunchKernelGGL((k_post_physics<1, true, false, false>), grid, dim3(threads), lds, as_stream(stream), a);
     } else {
         pose_pass();
-        hipLaunchKernelGGL((k_post_physics<1, false>), dim3(a.nb_post + a.nb_cast), dim3(threads), lds, as_stream(stream), a);
+        if (staged) hipLaunchKernelGGL((k_post_physics<1, false, true, false>), grid, dim3(threads), lds, as_stream(stream), a);
+        else if (a.obs_waves > 0) hipLaunchKernelGGL((k_post_physics<1, false, false, true>), grid, dim3(threads), lds, as_stream(stream), a);
+        else hipLaunchKernelGGL((k_post_physics<1, false, false, false>), grid, dim3(threads), lds, as_stream(stream), a);
     }
     MDP_LAUNCH_CHECK();
     return MDP_OK;
@@ -1693,10 +1764,16 @@ constexpr int kMaxDevices = 64;
 std::mutex g_scratch_mutex;
 double* g_scratch_ptr[kMaxDevices] = {};
 
-int post_noalloc_scratch(double** out) {
+// `program_device`: the device the caller's programs (and so its buffers and stream) live on.  Each GPU holds its own
+// copy of the array at its own address, and hipGetSymbolAddress answers for the CURRENT device: the two must agree,
+// else the kernel would be handed another GPU's address.
+int post_noalloc_scratch(int program_device, double** out) {
     int dev = -1;
     MDP_CHECK_HIP(hipGetDevice(&dev));
     MDP_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d out of range", dev);
+    MDP_REQUIRE(dev == program_device,
+                "noalloc: the current device (%d) is not the device the programs were created on (%d); call hipSetDevice first",
+                dev, program_device);
     std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[dev]) {
         double* p = nullptr;
@@ -1725,15 +1802,16 @@ extern "C" int mdp_post_physics_step_with_reset_noalloc(int num_envs, const mdp_
                 "noalloc: %lld envs x %lld statistics rows need %lld doubles of scratch, the static array holds %d"
                 " (use mdp_post_physics_step_with_reset with a workspace of your own)",
                 (long long)num_envs, (long long)rows, (long long)need, (int)MDP_POST_NOALLOC_SCRATCH_DOUBLES);
+    MDP_REQUIRE(tr->termination->device == tr->reward->device, "noalloc: programs of different devices");
     double* ws = nullptr;
-    int rc = post_noalloc_scratch(&ws);
+    int rc = post_noalloc_scratch(tr->termination->device, &ws);
     if (rc != MDP_OK) return rc;
-    // The array keeps whatever the last call on this GPU left.  Only word 0 (the block ticket) must start at zero; the
-    // slots are fully rewritten by the blocks of this launch before its last block reads them.
-    MDP_CHECK_HIP(hipMemsetAsync(ws, 0, sizeof(double), as_stream(stream)));
+    // The array keeps whatever the last call on this GPU left.  Only word 0 (the block ticket) must start at zero -- the
+    // launch routine clears it once it has accepted the arguments; the slots are fully rewritten by the blocks of this
+    // launch before its last block reads them.
     mdp_post_reset_args_t r = *reset;
     r.log_sums = ws;
-    return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, &r, stream);
+    return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, &r, stream, true);
 }
 
 extern "C" int mdp_obs_postprocess(const mdp_term_t* term, int num_envs, float* data, int ld, uint64_t seed,

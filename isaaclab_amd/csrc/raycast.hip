@@ -766,10 +766,12 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
 #ifndef MDP_RCD_MIN_WAVES
 #define MDP_RCD_MIN_WAVES 1
 #endif
-template <int BATCH>
+template <int BATCH, bool STAGED>
 __global__ void __launch_bounds__(256, MDP_RCD_MIN_WAVES)
 k_raycaster_update_down(RaycasterUpdateArgs a, int epb, int slot_w) {
-    raycaster_update_down_blocks<BATCH>(a, epb, slot_w, blockIdx.x, gridDim.x);
+    extern __shared__ __align__(16) unsigned char s_stage[];
+    if constexpr (STAGED) raycaster_update_down_blocks_staged(a, epb, slot_w, blockIdx.x, gridDim.x, s_stage);
+    else raycaster_update_down_blocks<BATCH>(a, epb, slot_w, blockIdx.x, gridDim.x);
 }
 
 // RayCasterCamera._update_buffers_impl (ray_caster_camera.py:257-318): one thread per (env, ray) of the outdated envs.
@@ -906,16 +908,29 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
             int64_t c = b ? std::atoll(b) : 0;
             return c > 0 ? c : (int64_t)(1 << 20);
         }();
+        const char* stage_v = std::getenv("MDP_RC_STAGE");    // read at every call: tests flip it inside one process
+        const int stage_env = stage_v ? std::atoi(stage_v) : 0;
         RaycasterUpdateArgs ra;
+        std::memset(&ra, 0, sizeof(ra));
+        ra.stage = (stage_env != 0 && mesh->view.finite) ? 1 : 0;
+        const size_t stage_lds = ra.stage ? rc_stage_lds_bytes() : 0;
+        if (ra.stage && epb > (int)RCU_MAX_EPB_STAGED) {
+            epb = RCU_MAX_EPB_STAGED;
+            threads = ((epb * slot_w + 63) / 64) * 64;
+            blocks = ((int64_t)num_envs + epb - 1) / epb;
+        }
         ra.mesh = mesh->view; ra.N = num_envs; ra.R = num_rays; ra.pose = root_pose; ra.ld_pose = ld_pose;
         ra.pose_xyzw = pose_xyzw; ra.drift = drift; ra.starts_l = ray_starts_local; ra.dirs_l = ray_dirs_local;
         ra.max_dist = max_dist; ra.pos_w = pos_w; ra.quat_w = quat_w; ra.hits = ray_hits_w; ra.ts = timestamp;
         ra.ts_last = timestamp_last_update; ra.outdated = is_outdated; ra.scan = sc; ra.tick_dt = tick_dt;
         ra.period = update_period; ra.reset_mask = nullptr; ra.pose_ws = nullptr; ra.pose_ready = 0;
 #define RCD_LAUNCH(B)                                                                                             \
-    hipLaunchKernelGGL(k_raycaster_update_down<B>, dim3(grid_for(blocks, 1, block_cap)), dim3(threads), 0,        \
+    hipLaunchKernelGGL((k_raycaster_update_down<B, false>), dim3(grid_for(blocks, 1, block_cap)), dim3(threads), 0, \
                        as_stream(stream), ra, epb, slot_w)
-        if (batch == 1) RCD_LAUNCH(1); else if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
+        if (ra.stage)
+            hipLaunchKernelGGL((k_raycaster_update_down<1, true>), dim3(grid_for(blocks, 1, block_cap)), dim3(threads),
+                               stage_lds, as_stream(stream), ra, epb, slot_w);
+        else if (batch == 1) RCD_LAUNCH(1); else if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
 #undef RCD_LAUNCH
         MDP_LAUNCH_CHECK();
         return MDP_OK;

@@ -29,7 +29,32 @@ struct RaycasterUpdateArgs {
     const uint8_t* reset_mask;   // FLAGGED instantiation only (mdp_raycaster_update_flagged)
     float* pose_ws;              // (N, 8) {pos.xyz, yaw quaternion (w, z), cast flag, -, -}: filled by raycaster_pose_pass
     int pose_ready;              // 1: pose_ws holds this step's values (the pass ran in front of this launch)
+    int stage;                   // 1: the block stages the cell records its rays name in LDS (RcStage; the launch
+                                 // provides rc_stage_lds_bytes() of dynamic LDS), 0: every ray walks its cell on its own
 };
+
+// ---- cell records staged in LDS ----------------------------------------------------------------------------------
+// The rays of one scan fall on a patch of ~2 m^2: on stair treads, box tops and the border most of them name the SAME
+// few cell lists (cells with identical lists share one run of records, raycast.hip), and a ray that walks its list on
+// its own pays one dependent memory round trip per record -- with the slowest lane of the wave setting the pace -- for
+// bytes its neighbours fetch as well.  Staged form: every ray that needs records enters its list (keyed by the list's
+// offset) in a small hash table in LDS, the block then fetches the first RC_STAGE_K records of every DISTINCT list in one
+// cooperative, coalesced round trip (16 B per thread and load), and the rays walk out of LDS: same records, same order,
+// same arithmetic (mdp_rc_down_exact_record), so hits stay bit-identical.  A ray that finds no free slot, or whose walk
+// goes past the staged records, continues from global memory as before.
+#ifndef MDP_RC_STAGE_SLOTS
+#define MDP_RC_STAGE_SLOTS 64          // power of two
+#endif
+#ifndef MDP_RC_STAGE_K
+#define MDP_RC_STAGE_K 3
+#endif
+constexpr int RC_STAGE_SLOTS = MDP_RC_STAGE_SLOTS, RC_STAGE_K = MDP_RC_STAGE_K, RC_STAGE_PROBES = 4;
+struct RcStage {
+    float4 rec[RC_STAGE_SLOTS][RC_STAGE_K][4];   // 64-byte records, list order
+    int key[RC_STAGE_SLOTS];                     // list offset into cell_recs_down (records), -1 = free
+    int cnt[RC_STAGE_SLOTS];                     // records staged for the slot: min(list length, RC_STAGE_K)
+};
+constexpr size_t rc_stage_lds_bytes() { return sizeof(RcStage); }
 
 // height_scan observation column of ray r of env e, written by the cast kernels (mdp_height_scan_obs_t)
 // Generator stream of the height-scan noise: the per-step cast and the flagged recast after a reset read the same
@@ -57,6 +82,7 @@ __device__ __forceinline__ void scan_store(const mdp_height_scan_obs_t& sc, int 
 // lanes through LDS behind the block's single barrier; the ray lanes only rotate their start, walk one grid cell and
 // post-process their height.
 constexpr int RCU_MAX_EPB = 256;   // blockDim.x <= 1024 and num_rays >= 1; callers keep epb <= this
+constexpr int RCU_MAX_EPB_STAGED = 32;   // env slots per block of the staged routine
 
 // ray r of env e: start rotated by the yaw quaternion, one grid-cell walk, hit point and height_scan column stored
 template <int BATCH>
@@ -115,7 +141,7 @@ __device__ __forceinline__ void raycaster_env_bookkeeping(const RaycasterUpdateA
     float t_now = ts_in;
 #ifdef MDP_STAMPS
     if (pos.x == 1.2345e30f && dr.x == 1.0f && ts_in == last_in) return;   // waits for every input
-    MDP_STAMP(5);
+    if (!a.stage) MDP_STAMP(5);     // (the staged walk uses stamps 5 and 6 for its two barriers)
 #endif
     if (a.tick_dt > 0.0f) {
         t_now += a.tick_dt;
@@ -128,7 +154,7 @@ __device__ __forceinline__ void raycaster_env_bookkeeping(const RaycasterUpdateA
         Q4 qr = yaw_quat(q);
 #ifdef MDP_STAMPS
         if (qr.w == 1.2345e30f) return;
-        MDP_STAMP(6);
+        if (!a.stage) MDP_STAMP(6);
 #endif
         se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
         st3(a.pos_w + 3 * (int64_t)e, pos);
@@ -150,6 +176,117 @@ __device__ __forceinline__ void raycaster_pose_pass(const RaycasterUpdateArgs& a
     w[1] = float4{se[4], se[5], 0.0f, 0.0f};
 }
 
+// The rays [r0, r0 + slot_w) of the block's envs through the staged walk (RcStage above).  Every thread of the block
+// calls this (the barriers inside are block-wide); `live`: this lane casts ray r of env e.  The table's keys are free
+// (-1) on entry, behind a barrier, and are left in use: the caller frees them behind the barrier that ends its iteration.
+__device__ __forceinline__ void raycaster_down_rays_staged(const RaycasterUpdateArgs& a, RcStage* st, bool live, int e, int r,
+                                                           V3 pos, Q4 qr, uint64_t seed, uint64_t epoch) {
+    const mdp_mesh_view_t& m = a.mesh;
+    const int R = a.R;
+    const float inf = __builtin_inff();
+    V3 s{0.0f, 0.0f, 0.0f}, d{0.0f, 0.0f, -1.0f};
+    mdp_hit_t h; h.t = a.max_dist; h.face = -1;
+    int32_t b = 0, n = 0;
+    bool disjoint = false;
+    if (live) {
+        s = quat_apply(qr, ld3(a.starts_l + 3 * r));
+        s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
+        d = ld3(a.dirs_l + 3 * r);
+        // the cell's entry and the coarse patch entry are requested together: one round trip, not patch -> cell
+        int32_t c;
+        const bool cell_ok = mdp_rc_down_cell(&m, s.x, s.y, &c);
+        int2 cref{0, 0};
+        if (cell_ok) cref = reinterpret_cast<const int2*>(m.cell_start_down)[c];
+        bool patched = false;
+        int pcell;
+        if (m.patch_cells && mdp_rc_patch_cell(&m, s.x, s.y, &pcell)) {
+            const int4* pc = reinterpret_cast<const int4*>(m.patch_cells) + 2 * pcell;
+            const int4 c0 = pc[0], c1 = pc[1];
+            int vidx, ncols;
+            if (mdp_rc_patch_square(c0, c1, s.x, s.y, &vidx, &ncols)) {
+                const float4* V = reinterpret_cast<const float4*>(m.patch_verts) + vidx;
+                patched = mdp_rc_patch_eval(V[0], V[1], V[ncols], V[ncols + 1], s.x, s.y, s.z, d.z, a.max_dist, &h) != 0;
+            }
+        }
+        if (!patched) {
+            h.t = a.max_dist; h.face = -1;
+            if (cell_ok) { disjoint = cref.x < 0; b = MDP_RC_CELL_OFFSET(cref.x); n = cref.y; }
+        }
+    }
+    // ---- this ray's list into the table (linear probing; the first ray of a list owns the slot's count)
+    int slot = -1;
+    if (n > 0) {
+        unsigned hsh = ((unsigned)b * 2654435761u) >> 16;
+        for (int p = 0; p < RC_STAGE_PROBES; ++p) {
+            const int at = (int)((hsh + (unsigned)p) & (unsigned)(RC_STAGE_SLOTS - 1));
+            const int old = atomicCAS(&st->key[at], -1, (int)b);
+            if (old == -1) st->cnt[at] = n < RC_STAGE_K ? n : RC_STAGE_K;
+            if (old == -1 || old == (int)b) { slot = at; break; }
+        }
+    }
+    __syncthreads();
+    MDP_STAMP(5);
+    // ---- the distinct lists' first records, 16 bytes per thread and load, four loads of a thread in flight together
+    {
+        constexpr int CH = RC_STAGE_SLOTS * RC_STAGE_K * 4;
+        const float4* recs = reinterpret_cast<const float4*>(m.cell_recs_down);
+        float4* dst = &st->rec[0][0][0];
+        auto src_of = [&](int i) -> const float4* {     // chunk i of the table: its address in the record array, or null
+            if (i >= CH) return nullptr;
+            const int sl = i / (RC_STAGE_K * 4), ch = i - sl * (RC_STAGE_K * 4);
+            const int key = st->key[sl];
+            return (key >= 0 && (ch >> 2) < st->cnt[sl]) ? recs + ((int64_t)key * 4 + ch) : nullptr;
+        };
+        const int step = (int)blockDim.x;
+        for (int i = threadIdx.x; i < CH; i += 4 * step) {
+            const float4 *p0 = src_of(i), *p1 = src_of(i + step), *p2 = src_of(i + 2 * step), *p3 = src_of(i + 3 * step);
+            float4 v0, v1, v2, v3;
+            if (p0) v0 = *p0;
+            if (p1) v1 = *p1;
+            if (p2) v2 = *p2;
+            if (p3) v3 = *p3;
+            if (p0) dst[i] = v0;
+            if (p1) dst[i + step] = v1;
+            if (p2) dst[i + 2 * step] = v2;
+            if (p3) dst[i + 3 * step] = v3;
+        }
+    }
+    __syncthreads();
+    MDP_STAMP(6);
+    // ---- the walk of mdp_rc_grid_down_exact, record k from LDS while it is staged
+    if (n > 0) {
+        const float Sz = 1.0f / d.z;
+        bool stop = false;
+        for (int32_t k = 0; k < n && !stop; ++k) {
+            mdp_rec_t rec;
+            if (slot >= 0 && k < RC_STAGE_K) {
+                const float4* q = st->rec[slot][k];
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                rec.v[0] = q0.x; rec.v[1] = q0.y; rec.v[2] = q0.z; rec.v[3] = q0.w;
+                rec.v[4] = q1.x; rec.v[5] = q1.y; rec.v[6] = q1.z; rec.v[7] = q1.w;
+                rec.v[8] = q2.x; rec.v[9] = q2.y; rec.v[10] = q2.z; rec.v[11] = q2.w;
+                rec.v[12] = q3.x;
+            } else {
+                rec = mdp_rc_load_rec(m.cell_recs_down + MDP_RC_REC_STRIDE * (int64_t)(b + k));
+            }
+            stop = mdp_rc_down_exact_record(rec.v, s.x, s.y, s.z, Sz, disjoint, &h);
+        }
+    }
+    MDP_STAMP(4);
+    if (live) {
+        float* o = a.hits + ((int64_t)e * R + r) * 3;
+        float hz = inf;
+        if (h.face >= 0) {
+            hz = s.z + h.t * d.z;
+            o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = hz;
+        } else {
+            o[0] = inf; o[1] = inf; o[2] = inf;
+        }
+        if (a.scan.obs) scan_store(a.scan, e, r, R, pos.z, hz, seed, epoch);
+    }
+}
+
+// `stage_lds`: rc_stage_lds_bytes() of (dynamic) LDS, 16-byte aligned, when a.stage is set
 template <int BATCH>
 __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpdateArgs& a, int epb, int slot_w,
                                                              unsigned block, unsigned nblocks) {
@@ -194,6 +331,63 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
             for (int r = lr; r < R; r += slot_w) raycaster_down_ray<BATCH>(a, e, r, pos, qr, seed, epoch);
         }
         if (!a.pose_ready) __syncthreads();   // s_env is rewritten by the next env group
+    }
+    if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
+}
+
+// The same block routine with the staged walk (the host sets a.stage, picks the kernel instantiation that calls this
+// one and provides rc_stage_lds_bytes() of dynamic LDS at `stage_lds`, 16-byte aligned; meshes with non-finite
+// vertices are not staged).  A function of its own: the per-ray routine above stays exactly as it was measured.
+__device__ __forceinline__ void raycaster_update_down_blocks_staged(const RaycasterUpdateArgs& a, int epb, int slot_w,
+                                                                    unsigned block, unsigned nblocks,
+                                                                    unsigned char* stage_lds) {
+    __shared__ float s_senv[RCU_MAX_EPB_STAGED][6];   // pos.xyz, yaw quaternion (w, z), cast flag
+    RcStage* st = reinterpret_cast<RcStage*>(stage_lds);
+    const int N = a.N, R = a.R;
+    float* __restrict__ hits = a.hits;
+    const mdp_height_scan_obs_t& scan = a.scan;
+    const int le = threadIdx.x / slot_w;
+    const int lr = threadIdx.x - le * slot_w;
+    uint64_t seed = 0, epoch = 0;
+    if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + block]; }
+    for (int base = block * epb; base < N; base += nblocks * epb) {
+        const int e = base + le;
+        const bool active = le < epb && e < N;
+        float sv[6] = {0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+        // free the table (visible behind the barrier below)
+        for (int i = threadIdx.x; i < RC_STAGE_SLOTS; i += blockDim.x) st->key[i] = -1;
+        if (a.pose_ready) {
+            if (active) {
+                const float4* w = reinterpret_cast<const float4*>(a.pose_ws + 8 * (int64_t)e);
+                const float4 w0 = w[0], w1 = w[1];
+                sv[0] = w0.x; sv[1] = w0.y; sv[2] = w0.z; sv[3] = w0.w; sv[4] = w1.x; sv[5] = w1.y;
+            }
+            __syncthreads();
+        } else {
+            if (active && lr == 0) raycaster_env_bookkeeping(a, e, s_senv[le]);
+            __syncthreads();
+            const float* sl = s_senv[active ? le : 0];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sv[k] = sl[k];
+        }
+        MDP_STAMP(2);
+        const bool od = active && sv[5] != 0.0f;
+        if (active && !od && scan.obs) {
+            float sz = a.pos_w[3 * (int64_t)e + 2];
+            for (int r = lr; r < R; r += slot_w) scan_store(scan, e, r, R, sz, hits[((int64_t)e * R + r) * 3 + 2], seed, epoch);
+        }
+        const V3 pos = V3{sv[0], sv[1], sv[2]};
+        const Q4 qr = Q4{sv[3], 0.0f, 0.0f, sv[4]};
+        MDP_STAMP(3);
+        for (int r0 = 0; r0 < R; r0 += slot_w) {          // the same trip count for every thread of the block
+            if (r0 > 0) {
+                __syncthreads();                          // the previous group's walks are through: free the table
+                for (int i = threadIdx.x; i < RC_STAGE_SLOTS; i += blockDim.x) st->key[i] = -1;
+                __syncthreads();
+            }
+            raycaster_down_rays_staged(a, st, od && r0 + lr < R, e, r0 + lr, pos, qr, seed, epoch);
+        }
+        __syncthreads();                                  // s_senv and the table are rewritten by the next env group
     }
     if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
 }

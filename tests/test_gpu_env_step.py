@@ -61,6 +61,43 @@ def test_anymal_d_flat(device, n, persistent):
     compare(outs, replay_oracle(rec, 6))
 
 
+@pytest.mark.parametrize("obs_waves", (0, 1, 4, 6, 11))
+def test_flat_post_physics_wave_roles(device, obs_waves, monkeypatch):
+    """The manager blocks of a launch without cast blocks are 12 waves wide; `obs_waves` of them write the observations
+    while the others evaluate the reward terms (k_post_physics<.., ROLES>; default 6 at this size).  Every split gives
+    the oracle's step and the same bits as every other split (0: all waves do every phase, the observation operands
+    that lie in the command buffer still come from the block's LDS copy of the new command)."""
+    from oracle.harness import replay_oracle
+
+    monkeypatch.setenv("MDP_POST_OBS_WAVES", str(obs_waves))
+    env, rec, outs = run_env("anymal_d_flat", 203, 6, device, seed=13, persistent=True)
+    assert getattr(env, "_single_launch_steps", 0) == 5
+    compare(outs, replay_oracle(rec, 6))
+    monkeypatch.delenv("MDP_POST_OBS_WAVES")
+    _, _, base = run_env("anymal_d_flat", 203, 6, device, seed=13, persistent=True)
+    for a, b in zip(outs, base):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+
+
+def test_staged_cast_in_the_post_physics_launch(device, monkeypatch):
+    """MDP_RC_STAGE=1: the cast blocks stage the cell records their rays name in LDS (raycaster_update_device.hpp,
+    RcStage) instead of one walk per ray -- same records, same order, same arithmetic: the step's outputs and the
+    sensor's hit points are bit-identical to the per-ray walk's."""
+    runs = []
+    for stage in ("1", "0"):
+        monkeypatch.setenv("MDP_RC_STAGE", stage)
+        env, rec, outs = run_env("anymal_d_rough", 203, 4, device, seed=14, small_terrain=True, persistent=True,
+                                 scan_in_cast=True, mesh_accel="grid")
+        assert getattr(env, "_single_launch_steps", 0) == 3
+        runs.append((outs, to_np(env.scene["height_scanner"].data.ray_hits_w)))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+    assert np.isfinite(runs[0][1]).all()
+
+
 @pytest.mark.parametrize("n,fuse_cast,fused,persistent,scan_in_cast,single_launch",
                          ((5, False, True, False, True, True), (128, False, True, True, True, False),
                           (128, True, True, False, True, True), (37, False, False, False, True, True),

@@ -166,6 +166,40 @@ def test_full_terrain_height_scan_vs_independent_oracle(device, full_terrain):
     assert checked > 2000
 
 
+def test_full_terrain_staged_cast_equals_per_ray_walk(device, full_terrain, monkeypatch):
+    """MDP_RC_STAGE=1 (cell records of a block's rays staged in LDS, `raycaster_down_rays_staged`) against the per-ray
+    walk on ALL 765,952 rays of 4096 envs on the full terrain, two pose sets (one of them with every env on one spot:
+    every ray of a block in one hash slot chain): hit points bit for bit, misses included."""
+    import torch
+
+    from isaaclab_amd import _lib as L
+    from oracle import mdp_np as P
+
+    terrain, mesh, soup, caster = full_terrain
+    n = 4096
+    starts, dirs = P.grid_pattern(0.1, [1.6, 1.0])
+    starts = starts + np.array([0, 0, 20.0], np.float32)
+    R = starts.shape[0]
+    d_starts, d_dirs = to_dev(starts, device), to_dev(dirs, device)
+    for seed in (23, 24):
+        pose, _ = _poses(terrain, n, seed=seed)
+        if seed == 24:
+            pose[1::2] = pose[1]      # half of the envs on one spot, the others spread out
+        d_pose = to_dev(pose, device)
+        got = []
+        for stage in ("1", "0"):
+            monkeypatch.setenv("MDP_RC_STAGE", stage)
+            pos_w, quat_w = torch.zeros(n, 3, device=device), torch.zeros(n, 4, device=device)
+            hits = torch.full((n, R, 3), -7.0, device=device)
+            L.check(L.lib.mdp_raycaster_update(mesh.handle, n, R, d_pose.data_ptr(), 7, None, d_starts.data_ptr(),
+                                               d_dirs.data_ptr(), 1, 1, 1e6, pos_w.data_ptr(), quat_w.data_ptr(),
+                                               hits.data_ptr(), None, None, None, None, 0, 0.0, 0.0, L.stream(device)))
+            torch.cuda.synchronize()
+            got.append(to_np(hits))
+        np.testing.assert_array_equal(got[0], got[1])
+        assert np.isfinite(got[0]).all(-1).mean() > 0.8 and (got[0] != -7.0).all()
+
+
 def test_full_terrain_env_step_slice_vs_oracle(device, full_terrain):
     """The benchmark's env step (Anymal-C rough, 4096 envs, five launches incl. mdp_post_physics_step with its cast
     blocks) on the FULL terrain, three steps: an env slice replayed by the oracle on the same frames -- observations incl.

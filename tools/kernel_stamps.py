@@ -66,7 +66,12 @@ def cast_phases(st):
     d = np.diff(seq, axis=1)
     print("           cast phase medians (us): bookkeeping+barriers %.2f  pose+yaw %.2f  ray setup+cell walk %.2f  hit/obs stores %.2f"
           % tuple(np.median(d, axis=0)))
-    if (r[:, 5] != 0).any():   # finer stamps of the bookkeeping lane: 5 = its inputs arrived, 6 = yaw quaternion done
+    if os.environ.get("MDP_RC_STAGE", "1") != "0" and (r[:, 5] != 0).any():
+        # staged walk: 5 = every ray's list is in the table (first barrier), 6 = records staged (second barrier)
+        fine = np.diff(r[:, [3, 5, 6, 4]] / 100.0, axis=1)
+        print("           staged walk (us): cell + patch lookups, table %.2f  -> cooperative record fetch %.2f  -> walk out of LDS %.2f"
+              % tuple(np.median(fine, axis=0)))
+    elif (r[:, 5] != 0).any():   # finer stamps of the bookkeeping lane: 5 = its inputs arrived, 6 = yaw quaternion done
         b = r[r[:, 5] != 0]
         fine = np.diff(b[:, [0, 5, 6, 2]] / 100.0, axis=1)
         print("           bookkeeping lane (us): block start -> inputs arrived %.2f  -> yaw quaternion %.2f  -> stores + barrier passed %.2f"
