@@ -1087,6 +1087,41 @@ typedef struct {
 } mdp_curriculum_terrain_t;
 int mdp_curriculum_terrain_levels_vel(int num_envs, const mdp_curriculum_terrain_t* args, void* stream);
 
+/* mdp_post_physics_step_with_reset with the task's terrain curriculum and event terms INSIDE the launch
+ * (manager_based_rl_env.py:214-235, 346-391 complete; event_manager.py:199-240): a manager block runs, for the envs its
+ * termination phase has just flagged, curriculum -> episode statistics -> buffer fills -> reset event terms (root state,
+ * then joints; EventManager's reset bookkeeping) -> CommandTerm.reset, then for all its envs the command update and the
+ * interval term (per-env timer tick; push_by_setting_velocity where it fired), then the observations -- the order of the
+ * reference, with the arithmetic of the stand-alone mdp_event_* / mdp_curriculum_* launches (same device routines, same
+ * generator words: one epoch per env and term).  Members that are NULL are skipped; the env_mask members of the term
+ * structs are ignored (the launch's own `dones` / the timers decide), and so are curriculum->mean_level / mean_ws: with a
+ * curriculum the statistics get one more row, log[1 + Tr + 2 + Tt] = mean terrain level over ALL envs
+ * (curriculums.py:55), and log_sums holds 1 + (2 + Tr + 2 + Tt) * ceil(num_envs / 8) doubles.  The event terms move the
+ * robot under the cast blocks of the same launch, so -- as without events -- the caller follows the launch with
+ * mdp_raycaster_update_flagged(dones), which casts the reset envs again from their new pose.  Interval timers shared by
+ * all envs (is_global_time) are not covered: use the stand-alone launches. */
+typedef struct {
+    const mdp_curriculum_terrain_t* curriculum;       /* terrain_levels_vel, or NULL */
+    const mdp_event_root_state_t* reset_root_state;   /* mode "reset": reset_root_state_uniform, or NULL */
+    const mdp_event_joints_t* reset_joints;           /* mode "reset": reset_joints_by_scale / _by_offset (after the root state), or NULL */
+    const mdp_event_reset_mark_t* reset_mark;         /* EventManager bookkeeping of the reset terms, or NULL */
+    const mdp_event_push_t* push;                     /* mode "interval": push_by_setting_velocity, or NULL */
+    float* push_time_left;                            /* (N) timers of the interval term */
+    float push_lo, push_scale;                        /* resampled interval = u * scale + lo */
+    const float* push_tick_u;                         /* (N) injected uniforms of the resampling, or NULL */
+    uint64_t* push_tick_rng;                          /* 1 + N generator words (see the event terms), or NULL with push_tick_u */
+    uint8_t* push_trigger;                            /* (N) out: 1 where the timer fired, or NULL */
+    float interval_dt;                                /* env step dt (event_manager.py:203) */
+    int32_t pad0;
+} mdp_post_events_t;
+int mdp_post_physics_step_with_reset_events(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                            const mdp_termination_reward_args_t* termination_reward,
+                                            const mdp_velocity_command_args_t* command,
+                                            const mdp_obs_args_t* observation,
+                                            const mdp_raycaster_update_args_t* cast,
+                                            const mdp_post_reset_args_t* reset, const mdp_post_events_t* events,
+                                            void* stream);
+
 /* Imu._update_buffers_impl (LAB/sensors/imu/imu.py:142-182; SURVEY.md 8f N4: a sensor that is pure math over the body
  * state) for the envs flagged in is_outdated (NULL = all; the flags are cleared and timestamp_last_update = timestamp,
  * sensor_base.py:284-293): pose of the sensor frame (offset applied), velocity of the link's centre of mass moved to

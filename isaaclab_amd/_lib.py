@@ -160,6 +160,16 @@ class MdpPostResetArgs(C.Structure):
                 ("log_sums", C.c_void_p), ("log", C.c_void_p)]
 
 
+class MdpPostEvents(C.Structure):
+    """Mirror of ``mdp_post_events_t``."""
+
+    _fields_ = [("curriculum", C.c_void_p), ("reset_root_state", C.c_void_p), ("reset_joints", C.c_void_p),
+                ("reset_mark", C.c_void_p), ("push", C.c_void_p), ("push_time_left", C.c_void_p),
+                ("push_lo", C.c_float), ("push_scale", C.c_float), ("push_tick_u", C.c_void_p),
+                ("push_tick_rng", C.c_void_p), ("push_trigger", C.c_void_p), ("interval_dt", C.c_float),
+                ("pad0", C.c_int32)]
+
+
 class MdpEventRootState(C.Structure):
     """Mirror of ``mdp_event_root_state_t``."""
 

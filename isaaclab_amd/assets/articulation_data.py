@@ -152,7 +152,19 @@ class ArticulationData:
         if self._body_acc_w.timestamp < self._sim_timestamp:
             self._body_acc_w.data.copy_(self._root_physx_view.get_link_accelerations())
             self._body_acc_w.timestamp = self._sim_timestamp
+        pending = self.__dict__.pop("_body_acc_zero", None)
+        if pending:
+            for mask, stamp in pending:
+                if stamp == self._sim_timestamp:       # (older entries: the buffer has been read again from the simulation)
+                    self._body_acc_w.data.masked_fill_(mask.bool().view(-1, 1, 1), 0.0)
         return self._body_acc_w.data
+
+    def defer_body_acc_zero(self, mask: torch.Tensor):
+        """``body_acc_w[env_ids] = 0`` of ``write_root_velocity_to_sim`` (articulation.py:418) for a launch that wrote the
+        root velocities of the envs flagged in ``mask`` (device, num_envs bytes, read when the buffer is next accessed)
+        without touching this lazily refreshed buffer: the rows are zeroed at the next read of this physics step, which
+        is all the reference's write can be seen by (the next step reads the accelerations from the simulation again)."""
+        self.__dict__.setdefault("_body_acc_zero", []).append((mask, self._sim_timestamp))
 
     @property
     def joint_pos(self):

@@ -10,49 +10,17 @@
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
 #include "uniforms_device.hpp"
+#include "events_device.hpp"
 
 using namespace mdp;
 
 namespace {
 
-// math.py:252-278
-__device__ __forceinline__ Q4 quat_from_euler_xyz(float roll, float pitch, float yaw) {
-    float cy = cosf(yaw * 0.5f), sy = sinf(yaw * 0.5f);
-    float cr = cosf(roll * 0.5f), sr = sinf(roll * 0.5f);
-    float cp = cosf(pitch * 0.5f), sp = sinf(pitch * 0.5f);
-    return Q4{cy * cr * cp + sy * sr * sp, cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp,
-              sy * cr * cp - cy * sr * sp};
-}
-
-__device__ __forceinline__ void zero_body_acc(float* body_acc_w, int num_bodies, int e) {
-    if (!body_acc_w) return;
-    float* p = body_acc_w + (int64_t)e * num_bodies * 6;
-    for (int i = 0; i < num_bodies * 6; ++i) p[i] = 0.0f;      // articulation.py:418
-}
-
 // events.py:638-680 + articulation.py:316-341, 400-420
 __global__ void k_reset_root_state_uniform(int N, mdp_event_root_state_t a) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N || (a.env_mask && !a.env_mask[e])) return;
-    Uniforms u = uniforms_for(a.injected_u, 12, a.rng_state, 0x45525354u, e);
-    const float* d = a.default_root_state + (int64_t)e * 13;
-    float s[6];
-    for (int k = 0; k < 6; ++k) s[k] = u(k) * a.pose_scale[k] + a.pose_lo[k];
-    V3 pos{(d[0] + a.env_origins[3 * e + 0]) + s[0], (d[1] + a.env_origins[3 * e + 1]) + s[1],
-           (d[2] + a.env_origins[3 * e + 2]) + s[2]};
-    Q4 q = quat_mul(ld4(d + 3), quat_from_euler_xyz(s[3], s[4], s[5]));
-    float v[6];
-    for (int k = 0; k < 6; ++k) v[k] = d[7 + k] + (u(6 + k) * a.vel_scale[k] + a.vel_lo[k]);
-    float* r = a.root_state_w + (int64_t)e * 13;
-    st3(r, pos);
-    st4(r + 3, q);
-    for (int k = 0; k < 6; ++k) r[7 + k] = v[k];
-    float* t = a.sim_root_transforms + (int64_t)e * 7;         // (x, y, z, qx, qy, qz, qw)
-    st3(t, pos);
-    t[3] = q.x; t[4] = q.y; t[5] = q.z; t[6] = q.w;
-    float* sv = a.sim_root_velocities + (int64_t)e * 6;
-    for (int k = 0; k < 6; ++k) sv[k] = v[k];
-    zero_body_acc(a.body_acc_w, a.num_bodies, e);
+    event_reset_root_state_env(a, e);
 }
 
 // events.py:802-866 + articulation.py:472-508, one thread per (env, joint).  The env's epoch word advances in the
@@ -68,36 +36,14 @@ __global__ void k_reset_joints(int N, mdp_event_joints_t a) {
     __syncthreads();
     if (!on) return;
     if (!a.injected_u && j == 0) a.rng_state[1 + e] = epoch + 1;
-    Uniforms u{a.injected_u, 2 * J, seed, epoch, 0x454a4e54u, e};
-    const int64_t i = (int64_t)e * J + j;
-    float sp = u(j) * a.pos_scale + a.pos_lo;
-    float sv = u(J + j) * a.vel_scale + a.vel_lo;
-    float q = a.mode == 0 ? a.default_joint_pos[i] * sp : a.default_joint_pos[i] + sp;
-    float qd = a.mode == 0 ? a.default_joint_vel[i] * sv : a.default_joint_vel[i] + sv;
-    q = tclamp(q, a.soft_joint_pos_limits[2 * i], a.soft_joint_pos_limits[2 * i + 1]);
-    float vl = a.soft_joint_vel_limits[i];
-    qd = tclamp(qd, -vl, vl);
-    a.joint_pos[i] = q;
-    a.joint_vel[i] = qd;
-    a.prev_joint_vel[i] = qd;
-    a.joint_acc[i] = 0.0f;
-    a.sim_dof_positions[(int64_t)e * a.ld_sim + j] = q;
-    a.sim_dof_velocities[(int64_t)e * a.ld_sim + j] = qd;
+    event_reset_joint(a, e, j, seed, epoch);
 }
 
 // events.py:610-635 + articulation.py:400-420
 __global__ void k_push_by_setting_velocity(int N, mdp_event_push_t a) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N || (a.env_mask && !a.env_mask[e])) return;
-    Uniforms u = uniforms_for(a.injected_u, 6, a.rng_state, 0x45505348u, e);
-    float* r = a.root_state_w + (int64_t)e * 13 + 7;
-    float* sv = a.sim_root_velocities + (int64_t)e * 6;
-    for (int k = 0; k < 6; ++k) {
-        float v = r[k] + (u(k) * a.vel_scale[k] + a.vel_lo[k]);
-        r[k] = v;
-        sv[k] = v;
-    }
-    zero_body_acc(a.body_acc_w, a.num_bodies, e);
+    event_push_env(a, e);
 }
 
 // event_manager.py:203-225, per-env timers
@@ -105,14 +51,7 @@ __global__ void k_interval_tick(int N, float* __restrict__ time_left, float dt, 
                                 const float* __restrict__ inj, uint64_t* rng_state, uint8_t* __restrict__ trigger) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= N) return;
-    float t = time_left[e] - dt;
-    bool fire = t < 1e-6f;
-    if (fire) {
-        Uniforms u = uniforms_for(inj, 1, rng_state, 0x45495654u, e);
-        t = u(0) * scale + lo;
-    }
-    time_left[e] = t;
-    trigger[e] = fire ? 1 : 0;
+    trigger[e] = event_interval_tick_env(time_left, dt, lo, scale, inj, rng_state, e, time_left[e]) ? 1 : 0;
 }
 
 // event_manager.py:209-216, one timer for all envs (is_global_time): a single block, the decision is taken once
@@ -132,33 +71,6 @@ __global__ void k_interval_tick_global(int N, float* time_left, float dt, float 
     __syncthreads();
     const uint8_t f = (uint8_t)s_fire;
     for (int e = threadIdx.x; e < N; e += blockDim.x) trigger[e] = f;
-}
-
-// curriculums.py:26-55 (terrain_levels_vel) + terrain_importer.py:307-324 (update_env_origins)
-__device__ __forceinline__ int64_t terrain_levels_vel_env(int e, const mdp_curriculum_terrain_t& a) {
-    const float* r = a.root_state_w + (int64_t)e * a.ld_state;
-    float* org = a.env_origins + 3 * (int64_t)e;
-    float distance = norm2(r[0] - org[0], r[1] - org[1]);
-    bool move_up = distance > a.half_tile_size;
-    bool move_down = distance < (norm2(a.command[3 * e], a.command[3 * e + 1]) * a.max_episode_length_s) * 0.5f;
-    move_down = move_down && !move_up;
-    int64_t level = a.terrain_levels[e] + (move_up ? 1 : 0) - (move_down ? 1 : 0);
-    if (level >= a.max_terrain_level) {
-        // robots that solve the last level are sent to a random one (torch.randint_like(levels, max_level))
-        if (a.injected_levels) {
-            level = a.injected_levels[e];
-        } else {
-            uint64_t seed = a.rng_state[0], epoch = a.rng_state[1 + e];
-            a.rng_state[1 + e] = epoch + 1;
-            level = (int64_t)(rng4(seed, epoch, 0x43544c56u, (uint64_t)e).x % (uint32_t)a.max_terrain_level);
-        }
-    } else if (level < 0) {
-        level = 0;
-    }
-    a.terrain_levels[e] = level;
-    const float* o = a.terrain_origins + ((int64_t)level * a.num_cols + a.terrain_types[e]) * 3;
-    org[0] = o[0]; org[1] = o[1]; org[2] = o[2];
-    return level;
 }
 
 // With mean_level set the launch also returns what the term returns, torch.mean(terrain_levels.float()) over ALL envs

@@ -16,6 +16,7 @@
 #include "raycaster_update_device.hpp"
 #include "scene_update_device.hpp"
 #include "command_device.hpp"
+#include "events_device.hpp"
 #include "stamps_device.hpp"
 
 #include <cstdlib>
@@ -905,6 +906,15 @@ struct PostArgs {
     int obs_waves;   // > 0: that many of a manager block's waves write the observations next to the reward phase
     // ---- reset branch (k_post_physics<.., true> only)
     const mdp_fill_t* fills; int num_fills; float max_episode_length_s; double* log_sums; float* log;
+    // ---- terrain curriculum and event terms inside the reset branch (mdp_post_physics_step_with_reset_events)
+    int has_cur, has_ev_root, has_ev_joints, has_ev_mark, has_ev_push;
+    mdp_curriculum_terrain_t cur;
+    mdp_event_root_state_t ev_root;
+    mdp_event_joints_t ev_joints;
+    mdp_event_reset_mark_t ev_mark;
+    mdp_event_push_t ev_push;
+    float* push_time_left; float push_lo, push_scale, interval_dt;
+    const float* push_tick_u; uint64_t* push_tick_rng; uint8_t* push_trigger;
 };
 
 // Both roles of the kernel are chains of dependent memory round trips, so the waves a CU can hold are its throughput:
@@ -1081,6 +1091,10 @@ k_post_physics(PostArgs a) {
     if (a.has_upd) scene_update_envs(a.upd, a.physics_dt, e0, e1);
     MDP_STAMP(1);
     const int e = lane < E ? e0 + lane : N;   // lanes beyond the block's envs idle through the term phases
+    // (reset branch with a terrain curriculum: the levels of ALL the block's envs go into the statistics; requested here,
+    // by the wave that runs the curriculum, several phases ahead of their use)
+    long long lvl_pre = 0;
+    if (RESET && a.has_cur && wave == (nwaves > 1 ? 1 : 0) && e < N) lvl_pre = (long long)a.cur.terrain_levels[e];
     // ---- episode_length_buf += 1 (manager_based_rl_env.py:199)
     if (a.len_inc && wave == 0 && e < N) a.len_inc[e] += 1;
     __threadfence_block();
@@ -1168,21 +1182,63 @@ k_post_physics(PostArgs a) {
         // statistics of the reset envs: row r of {count, Tr episode sums, 2 command metrics, Tt termination counts},
         // rows over the waves, envs over the lanes (one load per lane, no chain), wave sum
         const int rows = 1 + a.Tr + 2 + a.Tt;
+        const int slot_rows = rows + (a.has_cur ? 1 : 0);  // + the terrain levels of ALL the block's envs (curriculums.py:55)
         const bool mine = e < N && s_done[lane] != 0;
         __shared__ uint8_t s_list[64];                    // local ids of the block's done envs, s_nd of them
         __shared__ int s_nd;
+        // every block stores its row sums in a slot of its own (no atomics: the sums do not depend on block timing)
+        double* part = a.log_sums + 1 + (size_t)b * slot_rows;
         if (wave == 0) {
             const unsigned long long m = __ballot(mine);
             if (mine) s_list[__popcll(m & ((1ull << lane) - 1ull))] = (uint8_t)lane;
             if (lane == 0) s_nd = __popcll(m);
         }
-        // every block stores its row sums in a slot of its own (no atomics: the sums do not depend on block timing)
-        double* part = a.log_sums + 1 + (size_t)b * rows;
-        for (int r0 = wave; r0 < rows; r0 += 12 * nwaves) {
-            // twelve rows at a time: their loads are issued back to back, then the wave sums are taken
-            float v[12];
+        // CurriculumManager.compute(env_ids) comes first in _reset_idx (manager_based_rl_env.py:353): it reads the root
+        // position and the command of the episode that ends, and moves the env origin the root-state event reads.  Both,
+        // and EventManager's bookkeeping (event_manager.py:235-240), run HERE for the done envs, on the lanes of the
+        // block's second wave while the other waves fetch the statistics rows: nothing they write is read by the
+        // statistics, the fills or CommandTerm.reset, and the command update / observations sit behind two barriers
+        if (wave == (nwaves > 1 ? 1 : 0)) {
+            // everything the two routines read that depends on nothing they write is requested first: the done envs'
+            // chain is loads -> terrain origin of the new level -> stores, not one round trip per statement
+            TerrainLevelsIn cin{};
+            RootStateIn rin{};
+            const int64_t lvl_old = (int64_t)lvl_pre;
+            if (mine && a.has_cur) cin = terrain_levels_vel_load(e, a.cur);
+            if (mine && a.has_ev_root) rin = event_reset_root_state_load(a.ev_root, e);
+            V3 org{0.0f, 0.0f, 0.0f};
+            if (mine && a.has_ev_root && !a.has_cur) org = ld3(a.ev_root.env_origins + 3 * (int64_t)e);
+            if (a.has_cur) {
+                const int64_t lvl = mine ? terrain_levels_vel_apply(e, a.cur, cin, &org) : lvl_old;
+                double lv = e < N ? (double)lvl : 0.0;
+                for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o);
+                if (lane == 0)
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + rows),
+                                       (unsigned long long)__double_as_longlong(lv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (mine) {
+                if (a.has_ev_root) event_reset_root_state_apply(a.ev_root, e, rin, org);     // manager_based_rl_env.py:357-359
+                if (a.has_ev_mark) {
+                    // (constant indices into the argument struct: a runtime index would move the whole struct to scratch)
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
+                    for (int t = 0; t < MDP_EVENT_MARK_MAX_TERMS; ++t)
+                        if (t < a.ev_mark.num_terms) {
+                            a.ev_mark.last_triggered_step[t][e] = a.ev_mark.step_count;
+                            a.ev_mark.triggered_once[t][e] = 1;
+                        }
+                }
+            }
+        }
+#ifndef MDP_POST_ROWS_B
+#define MDP_POST_ROWS_B 4
+#endif
+        constexpr int ROWS_B = MDP_POST_ROWS_B;
+        for (int r0 = wave; r0 < rows; r0 += ROWS_B * nwaves) {
+            // ROWS_B rows at a time: their loads are issued back to back, then the wave sums are taken (same box, us/step
+            // with masked resets / with events: 105.0 / 112.1 with 4 rows, 105.7 / 112.6 with 12)
+            float v[ROWS_B];
+#pragma unroll
+            for (int j = 0; j < ROWS_B; ++j) {
                 const int r = r0 + j * nwaves;
                 v[j] = 0.0f;
                 if (mine && r < rows) {
@@ -1194,7 +1250,7 @@ k_post_physics(PostArgs a) {
                 }
             }
 #pragma unroll
-            for (int j = 0; j < 12; ++j) {
+            for (int j = 0; j < ROWS_B; ++j) {
                 const int r = r0 + j * nwaves;
                 double d = (double)v[j];
                 for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
@@ -1207,6 +1263,9 @@ k_post_physics(PostArgs a) {
         }
         __builtin_amdgcn_s_waitcnt(0);                    // those stores are acknowledged before the block takes its ticket
         __syncthreads();                                  // statistics read before anything is zeroed
+#ifdef MDP_STAMPS_RESET_FINE
+        MDP_STAMP(1);                                     // (diagnostic: slots 1 / 2 re-used for the reset section)
+#endif
         // the last manager block to get here will add the slots up and publish the log values -- at the very end of its
         // own work: the sums sit in memory, several round trips away, and nothing in this launch waits for the log
         unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.log_sums);
@@ -1215,8 +1274,12 @@ k_post_physics(PostArgs a) {
                      (unsigned long long)a.nb_post;
         // the buffers _reset_idx zeroes, for the done envs of this block (mdp_fill_t records, see mdp_masked_fill)
         // (done env, buffer) pairs over the waves, lanes over the elements (nothing to do in a block without done envs)
+        // Wave 0 goes straight to CommandTerm.reset below (a round trip of its own); the other waves share the fills and
+        // the joint-state event
         const int nd = s_nd;
-        for (int idx = wave; idx < nd * a.num_fills; idx += nwaves) {
+        const int fwaves = (a.has_cmd && nwaves > 1) ? nwaves - 1 : nwaves;
+        const int fwave = fwaves < nwaves ? wave - 1 : wave;
+        for (int idx = fwave < 0 ? nd * a.num_fills : fwave; idx < nd * a.num_fills; idx += fwaves) {
             const int j = idx / a.num_fills, fi = idx - j * a.num_fills;
             const int ee = e0 + s_list[j];
             const mdp_fill_t& f = fills[fi];
@@ -1226,6 +1289,23 @@ k_post_physics(PostArgs a) {
                 if (f.elem_bytes == 4) reinterpret_cast<uint32_t*>(f.ptr)[at] = (uint32_t)f.value_bits;
                 else if (f.elem_bytes == 8) reinterpret_cast<uint64_t*>(f.ptr)[at] = f.value_bits;
                 else reinterpret_cast<uint8_t*>(f.ptr)[at] = (uint8_t)f.value_bits;
+            }
+        }
+        // the joint-state event of the done envs (events.py:802-866): the same waves over the envs (last wave first),
+        // lanes over the joints
+        if (a.has_ev_joints && fwave >= 0) {
+            for (int j0 = fwaves - 1 - fwave; j0 < nd; j0 += fwaves) {
+                const int ee = e0 + s_list[j0];
+                uint64_t jseed = 0, jepoch = 0;
+                if (!a.ev_joints.injected_u) { jseed = a.ev_joints.rng_state[0]; jepoch = a.ev_joints.rng_state[1 + ee]; }
+                // the first 64 joints' inputs are requested with the generator words (one round trip)
+                const bool first = lane < a.ev_joints.num_joints;
+                JointResetIn jin{};
+                if (first) jin = event_reset_joint_load(a.ev_joints, ee, lane);
+                // (the store below carries the loaded epoch: every lane's load has returned before it is issued)
+                if (!a.ev_joints.injected_u && lane == 0) a.ev_joints.rng_state[1 + ee] = jepoch + 1;
+                if (first) event_reset_joint_apply(a.ev_joints, ee, lane, jseed, jepoch, jin);
+                for (int j = lane + 64; j < a.ev_joints.num_joints; j += 64) event_reset_joint(a.ev_joints, ee, j, jseed, jepoch);
             }
         }
         // CommandTerm.reset (command_manager.py:120-149): metrics, counter, resample
@@ -1238,6 +1318,9 @@ k_post_physics(PostArgs a) {
                                  a.cmd.injected_u, a.dones);
         }
         __threadfence_block();
+#ifdef MDP_STAMPS_RESET_FINE
+        MDP_STAMP(2);
+#endif
     }
     // ---- command_manager.compute(step_dt) (command_manager.py:151-187, velocity_command.py:111-160): after the
     // rewards, which read the previous command
@@ -1255,12 +1338,25 @@ k_post_physics(PostArgs a) {
         uint64_t seed = 0, epoch = 0;
         const bool gen = a.cmd.rng_state != nullptr && a.cmd.injected_u == nullptr;
         if (a.cmd.rng_state) { seed = a.cmd.rng_state[0]; epoch = a.cmd.rng_state[4 + b]; }
+        // (the interval term's timer is requested in front of the command update, used behind it)
+        const bool ticks = a.has_ev_push && wave == 0 && e < N;
+        const float push_tl = ticks ? a.push_time_left[e] : 0.0f;
+        PushIn pin{};
+        if (ticks) pin = event_push_load(a.ev_push, e);      // (the command update does not write the root state)
         if (wave == 0 && e < N)
             velocity_command_env(a.cmd.cfg, e, a.cmd.root_state, a.cmd.ld_state, a.cmd.vel_command_b, a.cmd.heading_target,
                                  a.cmd.is_heading_env, a.cmd.is_standing_env, a.cmd.time_left, a.cmd.command_counter,
                                  a.cmd.metric_error_vel_xy, a.cmd.metric_error_vel_yaw, a.cmd.dt, seed, epoch | (1ull << 62),
                                  a.cmd.injected_u, nullptr);
         if (gen && threadIdx.x == 0) a.cmd.rng_state[4 + b] = epoch + 1;
+        // EventManager.apply(mode="interval") (manager_based_rl_env.py:233-235): behind the command update, in front of
+        // the observations; per-env timers (event_manager.py:218-225)
+        if (a.has_ev_push && wave == 0 && e < N) {
+            const bool fire = event_interval_tick_env(a.push_time_left, a.interval_dt, a.push_lo, a.push_scale, a.push_tick_u,
+                                                      a.push_tick_rng, e, push_tl);
+            if (a.push_trigger) a.push_trigger[e] = fire ? 1 : 0;
+            if (fire) event_push_apply(a.ev_push, e, pin);
+        }
         __threadfence_block();
         __syncthreads();
     }
@@ -1273,7 +1369,8 @@ k_post_physics(PostArgs a) {
             // thread (r, p) adds the slots of blocks p, p + P, ... for row r (independent, coalesced loads, 32 in flight),
             // then the P partial sums of a row are added in order: the log does not depend on block timing
             __shared__ double s_red[256];
-            const int rows = 1 + a.Tr + 2 + a.Tt;
+            const int stat_rows = 1 + a.Tr + 2 + a.Tt;
+            const int rows = stat_rows + (a.has_cur ? 1 : 0);   // slot layout of the blocks: + the terrain-level sums
             double* s_sum = reinterpret_cast<double*>(s_val);
             const unsigned long long* all = reinterpret_cast<const unsigned long long*>(a.log_sums + 1);
             int P = (blockDim.x < 256 ? (int)blockDim.x : 256) / rows;
@@ -1282,16 +1379,16 @@ k_post_physics(PostArgs a) {
             if ((int)threadIdx.x < rows * P) {
                 const int p = threadIdx.x / rows, r = threadIdx.x - p * rows;
                 double v = 0.0;
-                for (unsigned b0 = p; b0 < a.nb_post; b0 += 32u * P) {
-                    unsigned long long w[32];
+                for (unsigned b0 = p; b0 < a.nb_post; b0 += 8u * P) {
+                    unsigned long long w[8];
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) {
+                    for (int j = 0; j < 8; ++j) {
                         const unsigned bb = b0 + (unsigned)j * P;
                         w[j] = bb < a.nb_post ? __hip_atomic_load(all + (size_t)bb * rows + r, __ATOMIC_RELAXED,
                                                                   __HIP_MEMORY_SCOPE_AGENT) : 0ull;
                     }
 #pragma unroll
-                    for (int j = 0; j < 32; ++j) v += __longlong_as_double((long long)w[j]);
+                    for (int j = 0; j < 8; ++j) v += __longlong_as_double((long long)w[j]);
                 }
                 s_red[threadIdx.x] = v;
             }
@@ -1306,7 +1403,8 @@ k_post_physics(PostArgs a) {
                 const int r = threadIdx.x;
                 const double cnt = s_sum[0], sum = s_sum[r];
                 float v;
-                if (r == 0 || r > a.Tr + 2) v = (float)sum;                 // counts
+                if (r == stat_rows) v = (float)sum * (1.0f / (float)N);     // torch.mean(terrain_levels.float()), curriculums.py:55
+                else if (r == 0 || r > a.Tr + 2) v = (float)sum;            // counts
                 else {
                     v = cnt > 0.0 ? (float)(sum / cnt) : 0.0f;              // torch.mean over the reset envs
                     if (r <= a.Tr) v = v / a.max_episode_length_s;
@@ -1544,7 +1642,8 @@ MDP_STAMP_SETTER(mdp_debug_stamps_programs)
 static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, float physics_dt,
                                const mdp_termination_reward_args_t* tr, const mdp_velocity_command_args_t* command,
                                const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
-                               const mdp_post_reset_args_t* reset, void* stream, bool clear_ticket = false) {
+                               const mdp_post_reset_args_t* reset, void* stream, bool clear_ticket = false,
+                               const mdp_post_events_t* events = nullptr) {
     MDP_REQUIRE(num_envs >= 0, "negative num_envs");
     MDP_REQUIRE(tr && tr->termination && tr->reward, "termination / reward programs required");
     mdp_program_t* tp = tr->termination;
@@ -1716,7 +1815,57 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
                     "reset: null pointer");
         MDP_REQUIRE(reset->max_episode_length_s > 0.0f, "reset: max_episode_length_s must be positive");
         MDP_REQUIRE(tr->dones && tr->term_dones && tr->episode_sums, "reset needs dones, term_dones and episode_sums");
-        MDP_REQUIRE(1 + a.Tr + 2 + a.Tt <= std::min(threads, 256), "reset: more statistics rows than a block reduces");
+        if (events) {
+            MDP_REQUIRE(command, "events: the launch needs the command term (the interval term runs behind its update)");
+            if (events->curriculum) {
+                const mdp_curriculum_terrain_t* c = events->curriculum;
+                MDP_REQUIRE(c->root_state_w && c->command && c->terrain_levels && c->terrain_types && c->terrain_origins &&
+                                c->env_origins, "events: curriculum: null pointer");
+                MDP_REQUIRE(c->ld_state >= 3 && c->max_terrain_level >= 1 && c->num_cols >= 1, "events: curriculum: bad shape");
+                MDP_REQUIRE(c->injected_levels || c->rng_state, "events: curriculum: need rng_state or injected_levels");
+                a.cur = *c; a.has_cur = 1;
+            }
+            if (events->reset_root_state) {
+                const mdp_event_root_state_t* r = events->reset_root_state;
+                MDP_REQUIRE(r->default_root_state && r->env_origins && r->root_state_w && r->sim_root_transforms &&
+                                r->sim_root_velocities, "events: root state: null pointer");
+                MDP_REQUIRE(r->injected_u || r->rng_state, "events: root state: need rng_state or injected_u");
+                MDP_REQUIRE(!r->body_acc_w || r->num_bodies > 0, "events: root state: body_acc_w without num_bodies");
+                a.ev_root = *r; a.has_ev_root = 1;
+            }
+            if (events->reset_joints) {
+                const mdp_event_joints_t* j = events->reset_joints;
+                MDP_REQUIRE(j->mode == 0 || j->mode == 1, "events: joints: mode must be 0 (by scale) or 1 (by offset)");
+                MDP_REQUIRE(j->num_joints > 0 && j->num_joints <= 128, "events: joints: num_joints out of range");
+                MDP_REQUIRE(j->default_joint_pos && j->default_joint_vel && j->soft_joint_pos_limits && j->soft_joint_vel_limits &&
+                                j->joint_pos && j->joint_vel && j->prev_joint_vel && j->joint_acc && j->sim_dof_positions &&
+                                j->sim_dof_velocities, "events: joints: null pointer");
+                MDP_REQUIRE(j->ld_sim >= j->num_joints, "events: joints: ld_sim < num_joints");
+                MDP_REQUIRE(j->injected_u || j->rng_state, "events: joints: need rng_state or injected_u");
+                a.ev_joints = *j; a.has_ev_joints = 1;
+            }
+            if (events->reset_mark) {
+                const mdp_event_reset_mark_t* m = events->reset_mark;
+                MDP_REQUIRE(m->num_terms >= 0 && m->num_terms <= MDP_EVENT_MARK_MAX_TERMS, "events: mark: at most %d terms",
+                            MDP_EVENT_MARK_MAX_TERMS);
+                for (int t = 0; t < m->num_terms; ++t)
+                    MDP_REQUIRE(m->last_triggered_step[t] && m->triggered_once[t], "events: mark: term %d: null buffer", t);
+                a.ev_mark = *m; a.has_ev_mark = m->num_terms > 0 ? 1 : 0;
+            }
+            if (events->push) {
+                const mdp_event_push_t* p = events->push;
+                MDP_REQUIRE(p->root_state_w && p->sim_root_velocities && events->push_time_left, "events: push: null pointer");
+                MDP_REQUIRE(p->injected_u || p->rng_state, "events: push: need rng_state or injected_u");
+                MDP_REQUIRE(events->push_tick_u || events->push_tick_rng, "events: push: the timers need push_tick_rng or push_tick_u");
+                MDP_REQUIRE(!p->body_acc_w || p->num_bodies > 0, "events: push: body_acc_w without num_bodies");
+                MDP_REQUIRE(events->interval_dt > 0.0f, "events: interval_dt must be positive");
+                a.ev_push = *p; a.has_ev_push = 1;
+                a.push_time_left = events->push_time_left; a.push_lo = events->push_lo; a.push_scale = events->push_scale;
+                a.interval_dt = events->interval_dt; a.push_tick_u = events->push_tick_u;
+                a.push_tick_rng = events->push_tick_rng; a.push_trigger = events->push_trigger;
+            }
+        }
+        MDP_REQUIRE(1 + a.Tr + 2 + a.Tt + a.has_cur <= std::min(threads, 256), "reset: more statistics rows than a block reduces");
         MDP_REQUIRE(reset->num_fills <= MDP_MAX_FILLS, "reset: more than MDP_MAX_FILLS buffers");
         MDP_REQUIRE(post_envs >= 8, "reset: the log_sums workspace is sized for blocks of >= 8 envs (MDP_POST_ENVS=%d)", post_envs);
         a.fills = reset->fills; a.num_fills = reset->num_fills; a.log = reset->log;
@@ -1741,6 +1890,18 @@ extern "C" int mdp_post_physics_step(int num_envs, const mdp_scene_update_t* upd
                                      const mdp_obs_args_t* observation, const mdp_raycaster_update_args_t* cast,
                                      void* stream) {
     return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, nullptr, stream);
+}
+
+extern "C" int mdp_post_physics_step_with_reset_events(int num_envs, const mdp_scene_update_t* update, float physics_dt,
+                                                       const mdp_termination_reward_args_t* tr,
+                                                       const mdp_velocity_command_args_t* command,
+                                                       const mdp_obs_args_t* observation,
+                                                       const mdp_raycaster_update_args_t* cast,
+                                                       const mdp_post_reset_args_t* reset, const mdp_post_events_t* events,
+                                                       void* stream) {
+    MDP_REQUIRE(reset, "reset arguments required");
+    MDP_REQUIRE(events, "event arguments required (mdp_post_physics_step_with_reset is the launch without them)");
+    return post_physics_launch(num_envs, update, physics_dt, tr, command, observation, cast, reset, stream, false, events);
 }
 
 extern "C" int mdp_post_physics_step_with_reset(int num_envs, const mdp_scene_update_t* update, float physics_dt,

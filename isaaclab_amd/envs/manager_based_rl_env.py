@@ -38,6 +38,9 @@ class ManagerBasedRLEnv:
         self.fold_action = True         # process_action inside the first actuator launch of the step
         # last scene.update + terminations + rewards + command + observations + height-scan cast in one launch
         self.single_launch_post_physics = True
+        # masked auto-reset: the stock event terms and the terrain curriculum ride in the reset branch of the post-physics
+        # launch (False: one launch per term, as EventManager / CurriculumManager issue them)
+        self.fold_events = os.environ.get("MDP_FOLD_EVENTS", "1") != "0"
         self.post_reset_noalloc = False  # masked resets inside that launch: use the allocation-free entry point
         # extras["log"] of a masked reset: 0 = a fresh copy every step (the reference's dict of new tensors); R > 0 = the
         # launches publish into a ring of R buffers and extras["log"] holds views of them, valid for R - 1 further steps
@@ -159,9 +162,14 @@ class ManagerBasedRLEnv:
                        and not self._has_lazy_sensor() and os.environ.get("MDP_FLAT_SINGLE_LAUNCH") != "0")
         has_events = (any(m in self.event_manager.available_modes for m in ("reset", "interval"))
                       or len(self.curriculum_manager.active_terms) > 0)
+        fold_events = None
         if has_events:
-            # event terms write the robot state between rewards and observations: the stages run one after the other
-            split = early_cast = concurrent = flat_single = False
+            # event terms write the robot state between rewards and observations.  The stock terms of the velocity tasks ride
+            # in the reset branch of the post-physics launch (mdp_post_physics_step_with_reset_events); anything else: the
+            # stages run one after the other
+            fold_events = self._foldable_events() if (masked and self.fold_events) else None
+            if fold_events is None:
+                split = early_cast = concurrent = flat_single = False
         if masked:
             flat_single = False
         if concurrent and not split and not self._has_lazy_sensor() and os.environ.get("MDP_FORCE_CONCURRENT") != "1":
@@ -188,7 +196,7 @@ class ManagerBasedRLEnv:
                 self.scene.update(dt=self.physics_dt)
             # (with early_cast the last scene.update runs after the loop, next to or inside the post-physics launches)
         self.common_step_counter += 1
-        if early_cast and self.single_launch_post_physics and self._post_physics_single_launch(reset=masked):
+        if early_cast and self.single_launch_post_physics and self._post_physics_single_launch(reset=masked, events=fold_events):
             pass
         elif flat_single and self._post_physics_single_launch():
             pass
@@ -274,7 +282,103 @@ class ManagerBasedRLEnv:
                 return True
         return False
 
-    def _post_physics_single_launch(self, reset: bool = False) -> bool:
+    def _foldable_events(self):
+        """The task's reset / interval event terms and its curriculum as a plan for the reset branch of the post-physics
+        launch, or None when it holds anything but the stock terms in the order that launch runs them: (curriculum
+        ``terrain_levels_vel``,) ``reset_root_state_uniform``, ``reset_joints_by_scale`` / ``_by_offset``, and ONE interval
+        term ``push_by_setting_velocity`` with per-env timers (velocity_env_cfg.py:187-218, 269-272)."""
+        from . import mdp as M
+        from ..tasks.velocity.mdp.curriculums import terrain_levels_vel
+
+        em, cm = self.event_manager, self.curriculum_manager
+        if any(m not in ("reset", "interval", "startup", "prestartup") for m in em.available_modes):
+            return None
+        if any(em._mode_class_term_cfgs.get(m) for m in ("reset", "interval")) or cm._class_term_cfgs:
+            return None
+        plan = {"root": None, "joints": None, "push": None, "cur": None, "mark": []}
+        for i, cfg in enumerate(em._mode_term_cfgs.get("reset", [])):
+            if cfg.min_step_count_between_reset != 0:
+                return None
+            if cfg.func is M.reset_root_state_uniform and plan["root"] is None and plan["joints"] is None:
+                plan["root"] = cfg
+            elif cfg.func is M.reset_joints_by_scale and plan["joints"] is None:
+                plan["joints"] = (cfg, 0, "reset_joints_by_scale")
+            elif cfg.func is M.reset_joints_by_offset and plan["joints"] is None:
+                plan["joints"] = (cfg, 1, "reset_joints_by_offset")
+            else:
+                return None
+            plan["mark"].append(i)
+        if len(plan["mark"]) > 8:
+            return None
+        interval = em._mode_term_cfgs.get("interval", [])
+        if len(interval) > 1:
+            return None
+        if interval:
+            if interval[0].func is not M.push_by_setting_velocity or interval[0].is_global_time:
+                return None
+            plan["push"] = interval[0]
+        if len(cm._term_cfgs) > 1:
+            return None
+        if cm._term_cfgs:
+            if cm._term_cfgs[0].func is not terrain_levels_vel:
+                return None
+            plan["cur"] = (cm._term_names[0], cm._term_cfgs[0])
+        return plan
+
+    def _post_events_args(self, plan, keep: list):
+        """``mdp_post_events_t`` of a ``_foldable_events`` plan (the term structs are appended to ``keep``)."""
+        import ctypes as C
+
+        from .. import _lib as L
+        from ..managers.scene_entity_cfg import SceneEntityCfg
+        from ..tasks.velocity.mdp.curriculums import _fill_terrain_levels_vel
+        from .mdp.events import _fill_push, _fill_reset_joints, _fill_reset_root_state
+
+        em = self.event_manager
+        robot = SceneEntityCfg("robot")
+        ev = L.MdpPostEvents()
+        if plan["cur"] is not None:
+            a, _ = _fill_terrain_levels_vel(self, None, plan["cur"][1].params.get("asset_cfg", robot), keep)
+            keep.append(a)
+            ev.curriculum = C.addressof(a)
+        if plan["root"] is not None:
+            pr = plan["root"].params
+            a = _fill_reset_root_state(self, None, pr["pose_range"], pr["velocity_range"], pr.get("asset_cfg", robot), keep,
+                                       body_acc=False)
+            keep.append(a)
+            ev.reset_root_state = C.addressof(a)
+        if plan["joints"] is not None:
+            cfg, mode, name = plan["joints"]
+            pr = cfg.params
+            a = _fill_reset_joints(self, None, pr["position_range"], pr["velocity_range"], pr.get("asset_cfg", robot), mode,
+                                   name, keep)
+            keep.append(a)
+            ev.reset_joints = C.addressof(a)
+        if plan["mark"]:
+            a = L.MdpEventResetMark()
+            a.num_terms, a.step_count = len(plan["mark"]), int(self._sim_step_counter // self.cfg.decimation)
+            for k, i in enumerate(plan["mark"]):
+                a.last_triggered_step[k] = em._reset_term_last_triggered_step_id[i].data_ptr()
+                a.triggered_once[k] = em._reset_term_last_triggered_once[i].data_ptr()
+            keep.append(a)
+            ev.reset_mark = C.addressof(a)
+        if plan["push"] is not None:
+            cfg = plan["push"]
+            pr = cfg.params
+            a = _fill_push(self, None, pr["velocity_range"], pr.get("asset_cfg", robot), keep, body_acc=False)
+            keep.append(a)
+            ev.push = C.addressof(a)
+            lower, upper = cfg.interval_range_s
+            u = em.interval_uniforms.get(0)
+            ev.push_time_left = em._interval_term_time_left[0].data_ptr()
+            ev.push_lo, ev.push_scale = float(lower), float(upper - lower)
+            ev.push_tick_u = u.data_ptr() if u is not None else None
+            ev.push_tick_rng = None if u is not None else em._interval_rng[0].data_ptr()
+            ev.push_trigger = em._interval_masks[0].data_ptr()
+            ev.interval_dt = float(self.step_dt)
+        return ev
+
+    def _post_physics_single_launch(self, reset: bool = False, events=None) -> bool:
         """manager_based_rl_env.py:195-238 (last ``scene.update``, episode counter, terminations, rewards, command,
         observations incl. the height-scan cast) as ONE launch, ``mdp_post_physics_step``.  False when the task does not
         have the shape that entry point covers; the caller then uses the separate launches."""
@@ -324,24 +428,45 @@ class ManagerBasedRLEnv:
             # reset branch inside the launch; the ray caster's own reset follows it (see mdp_post_physics_step_with_reset)
             if getattr(self, "_post_reset_plan", None) is None:
                 self._post_reset_plan = self._masked_reset_plan(separate_sensor=sensor)
-                rows = 1 + len(rm.active_terms) + 2 + len(tm.active_terms)
+            # statistics rows: count, reward terms, two command metrics, termination terms (+ the mean terrain level)
+            rows = 1 + len(rm.active_terms) + 2 + len(tm.active_terms) + (1 if events and events["cur"] is not None else 0)
+            if getattr(self, "_post_reset_rows", None) != rows:
+                self._post_reset_rows = rows
                 # block ticket (zeroed once) + one slot of row sums per manager block of the launch
                 self._post_reset_sums = torch.zeros(1 + rows * ((self.num_envs + 7) // 8), dtype=torch.float64,
                                                     device=self.device)
                 self._post_reset_log = torch.zeros(rows, dtype=torch.float32, device=self.device)
+                self._post_reset_log_ring = None
             self._next_reset_log()
             _, count, _, blob = self._post_reset_plan
             ra = L.MdpPostResetArgs()
             ra.fills, ra.num_fills, ra.max_episode_length_s = blob.data_ptr(), count, float(self.max_episode_length_s)
             ra.log_sums, ra.log = self._post_reset_sums.data_ptr(), self._post_reset_log.data_ptr()
             launch = L.lib.mdp_post_physics_step_with_reset
-            if self.post_reset_noalloc:
+            if events is not None:
+                # curriculum + event terms inside the launch's reset branch (the order of _reset_idx / step)
+                keep: list = []
+                ev = self._post_events_args(events, keep)
+                L.check(L.lib.mdp_post_physics_step_with_reset_events(
+                    self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca), C.byref(obs_args),
+                    C.byref(cast), C.byref(ra), C.byref(ev), L.stream(self.device)))
+                from .mdp.events import _invalidate_body_state
+
+                _invalidate_body_state(art.data)              # articulation.py:337-339, 503-505
+                if events["root"] is not None:
+                    art.data.defer_body_acc_zero(tm._dones_buf)
+                if events["push"] is not None:
+                    art.data.defer_body_acc_zero(self.event_manager._interval_masks[0])
+                self.event_manager.reset(tm._dones_buf)
+                launch = None
+            elif self.post_reset_noalloc:
                 # callers that must not allocate (graph capture, serving loops): the library's own static scratch array
                 # takes the place of the workspace (mdp_post_physics_step_with_reset_noalloc; same kernels, same outputs)
                 ra.log_sums = None
                 launch = L.lib.mdp_post_physics_step_with_reset_noalloc
-            L.check(launch(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca), C.byref(obs_args),
-                           C.byref(cast), C.byref(ra), L.stream(self.device)))
+            if launch is not None:
+                L.check(launch(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
+                               C.byref(obs_args), C.byref(cast), C.byref(ra), L.stream(self.device)))
             # RayCaster.reset of the done envs + their recast (the observation's lazy evaluation in the reference) and the
             # reference's post-reset write_data_to_sim (gate: log[0] = number of reset envs).  Neither reads what the
             # other writes (sensor buffers + scan columns / actuator state + joint efforts), and both are short chains of
@@ -362,6 +487,12 @@ class ManagerBasedRLEnv:
                                                            L.stream(self.device)))
                 self.scene.write_data_to_sim(gate=self._post_reset_log)
             self._publish_reset_log()
+            if events is not None and events["cur"] is not None:
+                # the term's state (curriculum_manager.py:119-134) and its log line (:88-117): the launch's last row
+                name = events["cur"][0]
+                level = self._post_reset_log_last[rows - 1]
+                self.curriculum_manager._curriculum_state[name] = level
+                self.extras["log"]["Curriculum/" + name] = level
         else:
             L.check(L.lib.mdp_post_physics_step(self.num_envs, C.byref(d), float(self.physics_dt), C.byref(tr), C.byref(ca),
                                                 C.byref(obs_args), C.byref(cast) if cast is not None else None,
@@ -391,6 +522,7 @@ class ManagerBasedRLEnv:
         rm, tm, cm = self.reward_manager, self.termination_manager, self.command_manager
         # the launch overwrites its buffer next step and callers keep these: a copy, or this step's slot of the ring
         p = self._post_reset_log if int(self.reset_log_ring) > 0 else self._post_reset_log.clone()
+        self._post_reset_log_last = p
         nr = len(rm.active_terms)
         log = {}
         for i, name in enumerate(rm.active_terms):

@@ -69,12 +69,12 @@ def _dict_range(rng: dict, lo_out, scale_out):
         scale_out[k] = float(np.float32(hi32 - lo32))
 
 
-def reset_root_state_uniform(env, env_ids, pose_range: dict, velocity_range: dict,
-                             asset_cfg: SceneEntityCfg = SceneEntityCfg("robot")):
-    """events.py:638-680."""
+def _fill_reset_root_state(env, env_ids, pose_range: dict, velocity_range: dict, asset_cfg: SceneEntityCfg, keep: list,
+                           body_acc: bool = True):
+    """``mdp_event_root_state_t`` of the term (no launch).  ``body_acc=False``: the caller zeroes ``body_acc_w`` itself
+    (the launch that carries the term defers it, ``ArticulationData.defer_body_acc_zero``)."""
     asset = env.scene[asset_cfg.name]
     d = asset.data
-    keep: list = []
     a = L.MdpEventRootState()
     a.env_mask = _mask_ptr(env, env_ids, keep)
     a.default_root_state, a.env_origins = d.default_root_state.data_ptr(), env.scene.env_origins.data_ptr()
@@ -86,15 +86,24 @@ def reset_root_state_uniform(env, env_ids, pose_range: dict, velocity_range: dic
     view = asset.root_physx_view
     a.root_state_w = d.root_state_w.data_ptr()           # refreshed first if stale, then overwritten for the envs
     a.sim_root_transforms, a.sim_root_velocities = view.get_root_transforms().data_ptr(), view.get_root_velocities().data_ptr()
-    a.body_acc_w, a.num_bodies = d.body_acc_w.data_ptr(), asset.num_bodies
+    if body_acc:
+        a.body_acc_w, a.num_bodies = d.body_acc_w.data_ptr(), asset.num_bodies
+    return a
+
+
+def reset_root_state_uniform(env, env_ids, pose_range: dict, velocity_range: dict,
+                             asset_cfg: SceneEntityCfg = SceneEntityCfg("robot")):
+    """events.py:638-680."""
+    keep: list = []
+    a = _fill_reset_root_state(env, env_ids, pose_range, velocity_range, asset_cfg, keep)
     L.check(L.lib.mdp_event_reset_root_state_uniform(env.num_envs, C.byref(a), L.stream(env.device)))
-    _invalidate_body_state(d)
+    _invalidate_body_state(env.scene[asset_cfg.name].data)
 
 
-def _reset_joints(env, env_ids, position_range, velocity_range, asset_cfg, mode: int, name: str):
+def _fill_reset_joints(env, env_ids, position_range, velocity_range, asset_cfg, mode: int, name: str, keep: list):
+    """``mdp_event_joints_t`` of the term (no launch)."""
     asset = env.scene[asset_cfg.name]
     d = asset.data
-    keep: list = []
     a = L.MdpEventJoints()
     a.env_mask = _mask_ptr(env, env_ids, keep)
     a.num_joints, a.mode = asset.num_joints, mode
@@ -112,8 +121,14 @@ def _reset_joints(env, env_ids, position_range, velocity_range, asset_cfg, mode:
     view = asset.root_physx_view
     q, qd = view.get_dof_positions(), view.get_dof_velocities()
     a.sim_dof_positions, a.sim_dof_velocities, a.ld_sim = q.data_ptr(), qd.data_ptr(), q.stride(0)
+    return a
+
+
+def _reset_joints(env, env_ids, position_range, velocity_range, asset_cfg, mode: int, name: str):
+    keep: list = []
+    a = _fill_reset_joints(env, env_ids, position_range, velocity_range, asset_cfg, mode, name, keep)
     L.check(L.lib.mdp_event_reset_joints(env.num_envs, C.byref(a), L.stream(env.device)))
-    _invalidate_body_state(d)
+    _invalidate_body_state(env.scene[asset_cfg.name].data)
 
 
 def reset_joints_by_scale(env, env_ids, position_range: tuple, velocity_range: tuple,
@@ -128,11 +143,10 @@ def reset_joints_by_offset(env, env_ids, position_range: tuple, velocity_range: 
     _reset_joints(env, env_ids, position_range, velocity_range, asset_cfg, 1, "reset_joints_by_offset")
 
 
-def push_by_setting_velocity(env, env_ids, velocity_range: dict, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot")):
-    """events.py:610-635."""
+def _fill_push(env, env_ids, velocity_range: dict, asset_cfg: SceneEntityCfg, keep: list, body_acc: bool = True):
+    """``mdp_event_push_t`` of the term (no launch); ``body_acc`` as in ``_fill_reset_root_state``."""
     asset = env.scene[asset_cfg.name]
     d = asset.data
-    keep: list = []
     a = L.MdpEventPush()
     a.env_mask = _mask_ptr(env, env_ids, keep)
     _dict_range(velocity_range, a.vel_lo, a.vel_scale)
@@ -141,7 +155,15 @@ def push_by_setting_velocity(env, env_ids, velocity_range: dict, asset_cfg: Scen
     a.rng_state = None if u is not None else _state(env, ("push", asset_cfg.name), 4).data_ptr()
     a.root_state_w = d.root_state_w.data_ptr()
     a.sim_root_velocities = asset.root_physx_view.get_root_velocities().data_ptr()
-    a.body_acc_w, a.num_bodies = d.body_acc_w.data_ptr(), asset.num_bodies
+    if body_acc:
+        a.body_acc_w, a.num_bodies = d.body_acc_w.data_ptr(), asset.num_bodies
+    return a
+
+
+def push_by_setting_velocity(env, env_ids, velocity_range: dict, asset_cfg: SceneEntityCfg = SceneEntityCfg("robot")):
+    """events.py:610-635."""
+    keep: list = []
+    a = _fill_push(env, env_ids, velocity_range, asset_cfg, keep)
     L.check(L.lib.mdp_event_push_by_setting_velocity(env.num_envs, C.byref(a), L.stream(env.device)))
 
 

@@ -14,12 +14,12 @@ from ....envs.mdp.events import _mask_ptr, _state
 from ....managers.scene_entity_cfg import SceneEntityCfg
 
 
-def terrain_levels_vel(env, env_ids: Sequence[int], asset_cfg: SceneEntityCfg = SceneEntityCfg("robot")) -> torch.Tensor:
+def _fill_terrain_levels_vel(env, env_ids, asset_cfg: SceneEntityCfg, keep: list):
+    """``mdp_curriculum_terrain_t`` of the term without the mean-level members (no launch)."""
     asset = env.scene[asset_cfg.name]
     terrain = env.scene.terrain
     command = env.command_manager.get_command("base_velocity")
     st = terrain.device_state(env.device)
-    keep: list = []
     a = L.MdpCurriculumTerrain()
     a.env_mask = _mask_ptr(env, env_ids, keep)
     root = asset.data.root_state_w
@@ -36,6 +36,16 @@ def terrain_levels_vel(env, env_ids: Sequence[int], asset_cfg: SceneEntityCfg = 
     inj = getattr(env, "event_uniforms", {}).get("terrain_levels_vel")       # tests: the randint draws, (N,) int64
     a.injected_levels = inj.data_ptr() if inj is not None else None
     a.rng_state = None if inj is not None else _state(env, ("terrain_levels", asset_cfg.name), 7).data_ptr()
+    return a, st
+
+
+def terrain_levels_vel(env, env_ids: Sequence[int], asset_cfg: SceneEntityCfg = SceneEntityCfg("robot")) -> torch.Tensor:
+    keep: list = []
+    a, st = _fill_terrain_levels_vel(env, env_ids, asset_cfg, keep)
+    return _launch_terrain_levels_vel(env, a, st)
+
+
+def _launch_terrain_levels_vel(env, a, st) -> torch.Tensor:
     # the term's return value, torch.mean(terrain_levels.float()) (:55), written by the launch itself: a fresh
     # one-element tensor per call like the reference's, or a slot of a ring (env.reset_log_ring, no copy launch)
     ws = st.get("mean_ws")

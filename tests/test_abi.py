@@ -49,7 +49,7 @@ def test_struct_mirrors_match_header():
              ("mdp_termination_reward_args_t", L.MdpTerminationRewardArgs),
              ("mdp_velocity_command_args_t", L.MdpVelocityCommandArgs), ("mdp_obs_args_t", L.MdpObsArgs),
              ("mdp_raycaster_update_args_t", L.MdpRaycasterUpdateArgs),
-             ("mdp_joint_action_t", L.MdpJointAction), ("mdp_fill_t", L.MdpFill), ("mdp_post_reset_args_t", L.MdpPostResetArgs),
+             ("mdp_joint_action_t", L.MdpJointAction), ("mdp_fill_t", L.MdpFill), ("mdp_post_reset_args_t", L.MdpPostResetArgs), ("mdp_post_events_t", L.MdpPostEvents),
              ("mdp_event_root_state_t", L.MdpEventRootState), ("mdp_event_joints_t", L.MdpEventJoints),
              ("mdp_event_push_t", L.MdpEventPush), ("mdp_curriculum_terrain_t", L.MdpCurriculumTerrain), ("mdp_obs_normalize_t", L.MdpObsNormalize), ("mdp_imu_args_t", L.MdpImuArgs), ("mdp_frame_transformer_args_t", L.MdpFrameTransformerArgs),
              ("mdp_raycaster_camera_args_t", L.MdpRaycasterCameraArgs), ("mdp_event_reset_mark_t", L.MdpEventResetMark),

@@ -383,14 +383,17 @@ def test_flagged_recast_draws_its_own_noise(device):
         assert (x - y)[free].abs().max() <= 0.2 + 1e-6          # same hits, noise of +-0.1 each
 
 
-@pytest.mark.parametrize("name,mode", (("anymal_d_flat", True), ("anymal_d_flat", "masked"),
-                                       ("anymal_c_rough", "masked"), ("anymal_d_rough", True)))
-def test_reset_and_interval_events(device, name, mode):
+@pytest.mark.parametrize("name,mode,folded", (("anymal_d_flat", True, False), ("anymal_d_flat", "masked", False),
+                                              ("anymal_c_rough", "masked", False), ("anymal_d_rough", True, False),
+                                              ("anymal_c_rough", "masked", True), ("anymal_d_rough", "masked", True)))
+def test_reset_and_interval_events(device, name, mode, folded):
     """The step with the task's event terms (velocity_env_cfg.py:187-218): reset_root_state_uniform and
     reset_joints_by_scale for the envs that are done, push_by_setting_velocity when an env's interval timer fires.
     The events write robot state (root pose / velocity, joint state, zeroed joint_acc) that the command update, the
     height scan and the observations of the SAME step read -- everything must follow the oracle's restatement, on
-    the id-list path and on the sync-free masked path (device masks, mdp_event_* kernels)."""
+    the id-list path and on the sync-free masked path (device masks, mdp_event_* kernels).  ``folded``: curriculum and
+    event terms run INSIDE the reset branch of the post-physics launch (mdp_post_physics_step_with_reset_events: one
+    launch for everything after the last physics sub-step but the flagged recast and the gated actuator step)."""
     import torch
 
     from isaaclab_amd.envs.synthetic import make_velocity_env
@@ -398,8 +401,11 @@ def test_reset_and_interval_events(device, name, mode):
 
     n, steps = 64, 8
     kw = dict(small_terrain=True) if "rough" in name else {}
+    if folded:
+        kw["mesh_accel"] = "grid"
     env, rec = make_velocity_env(name, num_envs=n, device=str(device), steps=steps, seed=41, events=True, **kw)
     env.auto_reset = mode
+    env.observation_manager.persistent_output = folded
     g = torch.Generator().manual_seed(6)
     start = env.max_episode_length - torch.randint(1, steps + 3, (n,), generator=g)
     env.episode_length_buf.copy_(start)
@@ -439,6 +445,7 @@ def test_reset_and_interval_events(device, name, mode):
         assert_close(to_np(robot.data.joint_vel), orc._last_qd, rtol=1e-6, atol=1e-6, msg=f"joint_vel step {t}")
         assert_close(to_np(robot.data._previous_joint_vel), orc.prev_qd, rtol=1e-6, atol=1e-6)
         assert_close(to_np(env.event_manager._interval_term_time_left[0]), orc.push_time_left, rtol=1e-6, atol=1e-6)
+    assert getattr(env, "_single_launch_steps", 0) == (steps - 1 if folded else 0)
     assert pushed >= n // 2                                 # the interval timers did fire
     last = rec.field("dof_positions", steps * rec.decimation)
     assert np.abs(orc._last_q - last).max() > 0.05           # ... and the last step's resets left their joint state

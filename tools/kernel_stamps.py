@@ -85,7 +85,9 @@ def cast_phases(st):
 
 def main():
     n_envs = int(os.environ.get("STAMPS_ENVS", "4096"))     # stamp rows exist for 8192 blocks: up to ~7800 envs
-    env, rec = make_velocity_env("anymal_c_rough", num_envs=n_envs, device="cuda:0", steps=8, seed=5, inject_random=False)
+    events = os.environ.get("STAMPS_EVENTS", "0") == "1"    # ... with curriculum and event terms folded into it
+    env, rec = make_velocity_env("anymal_c_rough", num_envs=n_envs, device="cuda:0", steps=8, seed=5, inject_random=False,
+                                 events=events)
     env.observation_manager.persistent_output = True
     reset = os.environ.get("STAMPS_RESET", "0") == "1"      # the launch with the reset branch in it
     if reset:
@@ -107,7 +109,7 @@ def main():
     for rep in range(3):
         buf.zero_()
         torch.cuda.synchronize()
-        env._post_physics_single_launch(reset=reset)
+        env._post_physics_single_launch(reset=reset, events=env._foldable_events() if events else None)
         torch.cuda.synchronize()
         if rep == 2:
             show("k_post_physics", buf, {2: "managers", 1: "cast"}, {2: 5, 1: 1})
@@ -119,7 +121,13 @@ def main():
                 t0 = st[st[:, 0] != 0][:, 0].min()
                 d23 = (m[:, 3] - m[:, 2]) / 100.0
                 dones = env.termination_manager._dones_buf.cpu().numpy().astype(np.int64)
-                per_block = np.add.reduceat(dones, np.arange(0, len(dones), 24))[: len(m)]   # MDP_POST_ENVS = 24
+                E = -(-len(dones) // len(m))                                                  # envs per manager block
+                per_block = np.add.reduceat(dones, np.arange(0, len(dones), E))[: len(m)]
+                ends = (m[:, 5] - t0) / 100.0
+                print("           manager block ends (us): without done envs med %.2f max %.2f | with done envs med %.2f max %.2f"
+                      % (np.median(ends[per_block == 0]), ends[per_block == 0].max(),
+                         np.median(ends[per_block > 0]) if (per_block > 0).any() else 0.0,
+                         ends[per_block > 0].max() if (per_block > 0).any() else 0.0))
                 print("           rewards+reset phase: blocks without done envs med %.2f max %.2f | with done envs (%d blocks) med %.2f max %.2f"
                       % (np.median(d23[per_block == 0]), d23[per_block == 0].max(), int((per_block > 0).sum()),
                          np.median(d23[per_block > 0]) if (per_block > 0).any() else 0.0,
