@@ -970,6 +970,20 @@ int mdp_actuator_lstm_compute_gated(const float* gate, const mdp_net_desc_t* des
                                     float* hidden_state, float* cell_state, const float* effort_limit,
                                     const float* velocity_limit, float saturation_effort, float* computed_effort,
                                     float* applied_effort, void* stream);
+/* mdp_raycaster_update_flagged(reset_mask) and mdp_actuator_lstm_compute_gated(gate) -- the two launches that follow a
+ * post-physics launch with masked resets (sensor_base.py:182-195 + ray_caster.py:220-260 for the reset envs;
+ * manager_based_rl_env.py:214-222) -- as ONE launch: recast blocks in front, actuator blocks behind; the whole launch
+ * does nothing unless *gate > 0 (no env was reset: nothing to cast again either).  Covers the register-resident LSTM
+ * (hidden 8, <= 2 layers, linear decoder) and a cast that mdp_raycaster_update_flagged accepts, else
+ * MDP_ERR_UNSUPPORTED -- callers then issue the two launches. */
+int mdp_actuator_lstm_compute_gated_with_recast(const float* gate, const mdp_net_desc_t* desc, const float* packed_weights,
+                                                int num_envs, int num_joints, const float* q_des, int ld_q_des,
+                                                const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,
+                                                float* hidden_state, float* cell_state, const float* effort_limit,
+                                                const float* velocity_limit, float saturation_effort,
+                                                float* computed_effort, float* applied_effort,
+                                                const mdp_raycaster_update_args_t* cast, const uint8_t* reset_mask,
+                                                void* stream);
 int mdp_actuator_pd_compute_gated(const float* gate, int kind, int num_envs, int num_joints, const float* q_des,
                                   int ld_q_des, const float* qd_des, int ld_qd_des, const float* tau_ff, int ld_tau_ff,
                                   const float* joint_pos, int ld_pos, const float* joint_vel, int ld_vel,

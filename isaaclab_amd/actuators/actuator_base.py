@@ -144,6 +144,12 @@ class ActuatorBase(ABC):
     #: unless it is > 0); ``None`` for actuators that cannot take one.  Set by ``Articulation`` right before ``compute``
     supports_gate: bool = False
     pending_gate = None
+    #: (cast arguments, reset mask) of a flagged height-scan recast the next GATED ``compute`` carries in its launch
+    #: (``mdp_actuator_lstm_compute_gated_with_recast``); ``supports_recast()`` says whether this instance can
+    pending_recast = None
+
+    def supports_recast(self) -> bool:
+        return False
 
     def _take_joint_action(self, q_des_ptr, ld_q_des):
         """The pending joint action if this launch can process it (its processed buffer IS the position target the

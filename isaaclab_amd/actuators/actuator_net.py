@@ -106,6 +106,12 @@ class ActuatorNetLSTM(DCMotor):
         self.sea_hidden_state_per_env = self.sea_hidden_state.view(shape)
         self.sea_cell_state_per_env = self.sea_cell_state.view(shape)
 
+    def supports_recast(self) -> bool:
+        """The register-resident kernel's shape (hidden 8, <= 2 layers, linear decoder): its gated launch can carry the
+        flagged height-scan recast (``mdp_actuator_lstm_compute_gated_with_recast``)."""
+        n = self._net
+        return n.hidden == 8 and n.num_layers <= 2 and int(n.desc.mlp_layers) == 1
+
     def reset(self, env_ids: Sequence[int]):
         from ..utils.buffers.circular_buffer import _mask_from_ids
 
@@ -119,6 +125,20 @@ class ActuatorNetLSTM(DCMotor):
         qd, ld_qd = L.rows(joint_vel, "joint_vel")
         des, ld_des = L.rows(control_action.joint_positions, "joint_positions")
         gate, self.pending_gate = self.pending_gate, None
+        recast, self.pending_recast = self.pending_recast, None
+        if gate is not None and recast is not None:
+            # the flagged recast of the reset envs rides in front of the actuator blocks (one launch for the reset tail)
+            cast, reset_mask = recast
+            L.check(L.lib.mdp_actuator_lstm_compute_gated_with_recast(
+                gate.data_ptr(), C.byref(self._net.desc), self._net.packed.data_ptr(), self._num_envs, self.num_joints,
+                des.data_ptr(), ld_des, q.data_ptr(), ld_q, qd.data_ptr(), ld_qd, self.sea_hidden_state.data_ptr(),
+                self.sea_cell_state.data_ptr(), self.effort_limit.data_ptr(), self.velocity_limit.data_ptr(),
+                float(self._saturation_effort), self.computed_effort.data_ptr(), self.applied_effort.data_ptr(),
+                C.byref(cast), reset_mask.data_ptr(), L.stream(q.device)))
+            control_action.joint_efforts = self.applied_effort
+            control_action.joint_positions = None
+            control_action.joint_velocities = None
+            return control_action
         if gate is not None:
             L.check(L.lib.mdp_actuator_lstm_compute_gated(
                 gate.data_ptr(), C.byref(self._net.desc), self._net.packed.data_ptr(), self._num_envs, self.num_joints,

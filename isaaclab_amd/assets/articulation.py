@@ -86,13 +86,13 @@ class Articulation:
         for actuator in self.actuators.values():
             actuator.reset(env_ids)
 
-    def write_data_to_sim(self, carry_update=None, joint_action=None, gate=None):
+    def write_data_to_sim(self, carry_update=None, joint_action=None, gate=None, recast=None):
         """articulation.py:172-199 (the physics-side setters are out of scope).  ``carry_update = (desc, dt)`` lets the
         actuator launch run the scene update of the frame it reads in the same kernel (``can_carry_update``);
         ``joint_action`` (``L.MdpJointAction``) lets it process the action of the step (``can_fold_joint_action``).
         ``gate`` (device float): the whole call is conditional on ``gate > 0``, decided on the device -- the
         ``write_data_to_sim`` of manager_based_rl_env.py:221, which only runs in steps that reset an env."""
-        self._apply_actuator_model(carry_update, joint_action, gate)
+        self._apply_actuator_model(carry_update, joint_action, gate, recast)
 
     @property
     def can_fold_joint_action(self) -> bool:
@@ -271,7 +271,12 @@ class Articulation:
             return [self._merged_actuator]
         return list(self.actuators.values())
 
-    def _apply_actuator_model(self, carry_update=None, joint_action=None, gate=None):
+    def can_carry_recast(self) -> bool:
+        """True when the gated actuator step is ONE launch that can carry a flagged height-scan recast."""
+        acts = self._step_actuators()
+        return len(acts) == 1 and acts[0].supports_gate and acts[0].supports_recast()
+
+    def _apply_actuator_model(self, carry_update=None, joint_action=None, gate=None, recast=None):
         """articulation.py:1399-1436"""
         d = self._data
         if carry_update is not None:
@@ -288,6 +293,10 @@ class Articulation:
                 if not actuator.supports_gate or carry_update is not None or joint_action is not None:
                     raise NotImplementedError(f"device-conditional compute of {type(actuator).__name__}")
                 actuator.pending_gate = gate
+                if recast is not None:
+                    if not actuator.supports_recast():
+                        raise NotImplementedError(f"{type(actuator).__name__} cannot carry the flagged recast")
+                    actuator.pending_recast = recast
             control_action = ArticulationActions(
                 joint_positions=d.joint_pos_target[:, ji], joint_velocities=d.joint_vel_target[:, ji],
                 joint_efforts=d.joint_effort_target[:, ji], joint_indices=ji,

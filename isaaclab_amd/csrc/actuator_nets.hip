@@ -17,6 +17,8 @@
 #include "stamps_device.hpp"
 #include "joint_action_device.hpp"
 #include "scene_update_device.hpp"
+#include "raycaster_update_device.hpp"
+#include "raycaster_update_host.hpp"
 
 #include <cstdlib>
 #include <vector>
@@ -303,9 +305,16 @@ k_lstm(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsi
 // row's inputs -- ONE round trip, no LDS staging, no block barrier, no LDS read in front of each MFMA.  The generic
 // kernel above spends 63 % of its wave cycles parked on s_waitcnt (SQ_WAIT_ANY) for exactly those.  Same MFMA / gate
 // order as k_lstm: bit-identical outputs.
-template <int NL, bool SLICE>
+// RECAST (mdp_actuator_lstm_compute_gated_with_recast): the two launches that follow a post-physics launch with masked
+// resets -- RayCaster.reset + recast of the reset envs (mdp_raycaster_update_flagged) and the reference's conditional
+// write_data_to_sim (mdp_actuator_lstm_compute_gated) -- as ONE: the first nb_cast blocks are recast blocks (theirs is the
+// longer chain), the actuator blocks follow.  Neither role reads what the other writes, both do nothing when no env
+// was reset (*gate = number of reset envs), and on two streams their hand-over costs what the overlap gains
+// (masked-reset step: 106.2 us on two streams, 107.1 one after the other, 103.1 as one launch).  The instantiations
+// without RECAST contain none of it (cast / nb_cast are unused arguments there).
+template <int NL, bool SLICE, bool RECAST>
 __global__ void __launch_bounds__(256)
-k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact, int upd_envs,
+k_lstm8_reg(RaycasterUpdateArgs cast, unsigned nb_cast, mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root, unsigned nb_joint, unsigned nb_contact, int upd_envs,
             mdp_joint_action_t jact, NetDev net, const float* __restrict__ packed, int64_t rows, int J,
             const float* __restrict__ q_des, int ld_q_des, const float* __restrict__ q, int ld_q,
             const float* __restrict__ qd, int ld_qd, float* __restrict__ hs, float* __restrict__ cs,
@@ -315,8 +324,14 @@ k_lstm8_reg(mdp_scene_update_t upd, float dt, unsigned nb_act, unsigned nb_root,
     if (gate != nullptr && *gate <= 0.0f) return;      // mdp_actuator_lstm_compute_gated: nothing happens this launch
     // the carried scene update takes the FIRST blocks of the grid: its chain of dependent loads starts with the launch
     // instead of behind the actuator blocks
-    const unsigned nb_upd = gridDim.x - nb_act;
-    if (blockIdx.x < nb_upd) {
+    if (RECAST) {
+        if (blockIdx.x < nb_cast) {
+            raycaster_update_flagged_blocks<2>(cast, blockIdx.x);
+            return;
+        }
+    }
+    const unsigned nb_upd = RECAST ? nb_cast : gridDim.x - nb_act;
+    if (!RECAST && blockIdx.x < nb_upd) {
         MDP_STAMP(0, 1);
         scene_update_carried(upd, dt, blockIdx.x, nb_root, nb_joint, nb_contact, upd_envs);
         MDP_STAMP(1);
@@ -679,16 +694,18 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     // register-resident weights for the ANYdrive shape (MDP_LSTM_GENERIC=1 forces the LDS kernel: parity tests)
     static const bool force_generic = [] { const char* e = std::getenv("MDP_LSTM_GENERIC"); return e && e[0] == '1'; }();
     if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1 && rows < (1ll << 31)) {
+        RaycasterUpdateArgs no_cast;
+        std::memset(&no_cast, 0, sizeof(no_cast));
 #define L8(NLAYERS)                                                                                                 \
     do {                                                                                                            \
         if (upd_mode < 0)                                                                                           \
-            hipLaunchKernelGGL((k_lstm8_reg<NLAYERS, true>), grid8, block, 0, s, plan.d, dt, nb_act, plan.nb_root,  \
+            hipLaunchKernelGGL((k_lstm8_reg<NLAYERS, true, false>), grid8, block, 0, s, no_cast, 0u, plan.d, dt, nb_act, plan.nb_root,  \
                                plan.nb_joint, plan.nb_contact, upd_mode, act, net, packed_weights, rows, num_joints, \
                                q_des, ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state, cell_state,     \
                                effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort,    \
                                gate);                                                                               \
         else                                                                                                        \
-            hipLaunchKernelGGL((k_lstm8_reg<NLAYERS, false>), grid8, block, 0, s, plan.d, dt, nb_act, plan.nb_root, \
+            hipLaunchKernelGGL((k_lstm8_reg<NLAYERS, false, false>), grid8, block, 0, s, no_cast, 0u, plan.d, dt, nb_act, plan.nb_root, \
                                plan.nb_joint, plan.nb_contact, upd_mode, act, net, packed_weights, rows, num_joints, \
                                q_des, ld_q_des, joint_pos, ld_pos, joint_vel, ld_vel, hidden_state, cell_state,     \
                                effort_limit, velocity_limit, saturation_effort, computed_effort, applied_effort,    \
@@ -761,6 +778,54 @@ extern "C" int mdp_actuator_lstm_compute_gated(const float* gate, const mdp_net_
     return lstm_launch(nullptr, nullptr, 0.0f, desc, packed_weights, num_envs, num_joints, q_des, ld_q_des, joint_pos, ld_pos,
                        joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit, saturation_effort,
                        computed_effort, applied_effort, stream, gate);
+}
+
+extern "C" int mdp_actuator_lstm_compute_gated_with_recast(const float* gate, const mdp_net_desc_t* desc,
+                                                           const float* packed_weights, int num_envs, int num_joints,
+                                                           const float* q_des, int ld_q_des, const float* joint_pos,
+                                                           int ld_pos, const float* joint_vel, int ld_vel,
+                                                           float* hidden_state, float* cell_state,
+                                                           const float* effort_limit, const float* velocity_limit,
+                                                           float saturation_effort, float* computed_effort,
+                                                           float* applied_effort,
+                                                           const mdp_raycaster_update_args_t* cast,
+                                                           const uint8_t* reset_mask, void* stream) {
+    MDP_REQUIRE(gate, "null gate");
+    int rc = validate(desc);
+    if (rc != MDP_OK) return rc;
+    MDP_REQUIRE(packed_weights && q_des && joint_pos && joint_vel && hidden_state && cell_state && effort_limit &&
+                    velocity_limit && computed_effort && applied_effort, "null pointer");
+    const int64_t rows = (int64_t)num_envs * num_joints;
+    if (!(desc->lstm_layers >= 1 && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1 &&
+          rows > 0 && rows < (1ll << 31)))
+        return fail(MDP_ERR_UNSUPPORTED, "the fused reset tail covers the register-resident LSTM (hidden 8, <= 2 layers, linear decoder)");
+    MDP_REQUIRE(((uintptr_t)packed_weights & 15) == 0, "packed_weights must be 16-byte aligned");
+    RaycasterUpdateArgs ra;
+    rc = raycaster_flagged_args(num_envs, cast, reset_mask, &ra);
+    if (rc != MDP_OK) return rc;
+    MDP_REQUIRE(cast->num_rays <= 256, "the fused reset tail casts patterns of up to 256 rays per env block round");
+    NetDev net;
+    net.d = *desc;
+    make_layout(*desc, net.L);
+    const unsigned nb_act = net_grid(rows);
+    const unsigned nb_cast = (unsigned)(((int64_t)num_envs + RCF_ENVS - 1) / RCF_ENVS);
+    hipStream_t s = as_stream(stream);
+    mdp_scene_update_t no_upd;                   // (no carried update, no action in this launch)
+    mdp_joint_action_t no_act;
+    std::memset(&no_upd, 0, sizeof(no_upd));
+    std::memset(&no_act, 0, sizeof(no_act));
+    if (desc->lstm_layers == 1)
+        hipLaunchKernelGGL((k_lstm8_reg<1, false, true>), dim3(nb_cast + nb_act), dim3(256), 0, s, ra, nb_cast, no_upd, 0.0f,
+                           nb_act, 0u, 0u, 0u, 0, no_act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,
+                           ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
+                           saturation_effort, computed_effort, applied_effort, gate);
+    else
+        hipLaunchKernelGGL((k_lstm8_reg<2, false, true>), dim3(nb_cast + nb_act), dim3(256), 0, s, ra, nb_cast, no_upd, 0.0f,
+                           nb_act, 0u, 0u, 0u, 0, no_act, net, packed_weights, rows, num_joints, q_des, ld_q_des, joint_pos,
+                           ld_pos, joint_vel, ld_vel, hidden_state, cell_state, effort_limit, velocity_limit,
+                           saturation_effort, computed_effort, applied_effort, gate);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
 }
 
 extern "C" int mdp_actuator_lstm_reset(int layers, int hidden, int num_envs, int num_joints, float* hidden_state,

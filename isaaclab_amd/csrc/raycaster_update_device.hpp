@@ -121,6 +121,69 @@ __device__ __forceinline__ void raycaster_down_ray(const RaycasterUpdateArgs& a,
     if (a.scan.obs) scan_store(a.scan, e, r, R, pos.z, hz, seed, epoch, stream);
 }
 
+// The same ray for a launch that casts a handful of envs (the flagged recast after a reset): the dependent chain is what
+// such a launch costs, not its instruction count, so everything is requested as early as its address is known -- the
+// cell's entry together with the coarse patch entry, then the patch's four vertices together with the cell's first two
+// records -- and the walk of mdp_rc_grid_down_exact runs over what has arrived (further records, rare, one round trip
+// each): sensor pose -> two round trips instead of up to six.  Same records in the same order through the same
+// routines: the hit is bit-identical to raycaster_down_ray's.  Meshes with non-finite vertices take that routine.
+__device__ __forceinline__ void raycaster_down_ray_eager(const RaycasterUpdateArgs& a, int e, int r, V3 pos, Q4 qr,
+                                                         uint64_t seed, uint64_t epoch, uint32_t stream) {
+    const mdp_mesh_view_t& m = a.mesh;
+    const int R = a.R;
+    const float inf = __builtin_inff();
+    V3 s = quat_apply(qr, ld3(a.starts_l + 3 * r));
+    s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};
+    const V3 d = ld3(a.dirs_l + 3 * r);
+    // ---- round trip 1: cell entry + patch entry
+    int32_t c = 0;
+    const bool cell_ok = mdp_rc_down_cell(&m, s.x, s.y, &c);
+    int2 cref{0, 0};
+    if (cell_ok) cref = reinterpret_cast<const int2*>(m.cell_start_down)[c];
+    int pcell = 0;
+    const bool pc_ok = m.patch_cells && mdp_rc_patch_cell(&m, s.x, s.y, &pcell);
+    int4 c0{0, 0, 0, -1}, c1{0, 0, 0, 0};
+    if (pc_ok) {
+        const int4* pc = reinterpret_cast<const int4*>(m.patch_cells) + 2 * pcell;
+        c0 = pc[0]; c1 = pc[1];
+    }
+    // ---- round trip 2: lattice vertices + the first two records
+    int vidx = 0, ncols = 0;
+    const bool sq = pc_ok && mdp_rc_patch_square(c0, c1, s.x, s.y, &vidx, &ncols);
+    float4 v00{0, 0, 0, 0}, v01 = v00, v10 = v00, v11 = v00;
+    if (sq) {
+        const float4* V = reinterpret_cast<const float4*>(m.patch_verts) + vidx;
+        v00 = V[0]; v01 = V[1]; v10 = V[ncols]; v11 = V[ncols + 1];
+    }
+    const bool disjoint = cref.x < 0;
+    const int32_t b = MDP_RC_CELL_OFFSET(cref.x), n = cell_ok ? cref.y : 0;
+    mdp_rec_t R0{}, R1{};
+    if (n > 0) R0 = mdp_rc_load_rec(m.cell_recs_down + MDP_RC_REC_STRIDE * (int64_t)b);
+    if (n > 1) R1 = mdp_rc_load_rec(m.cell_recs_down + MDP_RC_REC_STRIDE * (int64_t)(b + 1));
+    // ---- the patch's answer, else the walk
+    mdp_hit_t h; h.t = a.max_dist; h.face = -1;
+    const bool patched = sq && mdp_rc_patch_eval(v00, v01, v10, v11, s.x, s.y, s.z, d.z, a.max_dist, &h) != 0;
+    if (!patched) {
+        h.t = a.max_dist; h.face = -1;
+        const float Sz = 1.0f / d.z;
+        bool stop = false;
+        for (int32_t k = 0; k < n && !stop; ++k) {
+            mdp_rec_t rec = k == 0 ? R0 : R1;
+            if (k > 1) rec = mdp_rc_load_rec(m.cell_recs_down + MDP_RC_REC_STRIDE * (int64_t)(b + k));
+            stop = mdp_rc_down_exact_record(rec.v, s.x, s.y, s.z, Sz, disjoint, &h);
+        }
+    }
+    float* o = a.hits + ((int64_t)e * R + r) * 3;
+    float hz = inf;
+    if (h.face >= 0) {
+        hz = s.z + h.t * d.z;
+        o[0] = s.x + h.t * d.x; o[1] = s.y + h.t * d.y; o[2] = hz;
+    } else {
+        o[0] = inf; o[1] = inf; o[2] = inf;
+    }
+    if (a.scan.obs) scan_store(a.scan, e, r, R, pos.z, hz, seed, epoch, stream);
+}
+
 // Per-env part of the update, one lane per env: SensorBase.update of this physics step (sensor_base.py:197-205), the
 // lazy-evaluation test (:284-293), sensor pose with drift and the yaw-only quaternion (ray_caster.py:220-240); writes
 // the sensor's own buffers and returns {pos.xyz, qr.w, qr.z, cast flag} in se[0..5].
@@ -451,8 +514,13 @@ __device__ __forceinline__ void raycaster_update_flagged_blocks(const RaycasterU
         any = true;
         const V3 pos = V3{se[0], se[1], se[2]};
         const Q4 qr = Q4{se[3], 0.0f, 0.0f, se[4]};
-        for (int r = threadIdx.x; r < R; r += blockDim.x)
-            raycaster_down_ray<BATCH>(a, base + le, r, pos, qr, seed, epoch, SCAN_STREAM_FLAGGED);
+        if (a.mesh.finite) {
+            for (int r = threadIdx.x; r < R; r += blockDim.x)
+                raycaster_down_ray_eager(a, base + le, r, pos, qr, seed, epoch, SCAN_STREAM_FLAGGED);
+        } else {
+            for (int r = threadIdx.x; r < R; r += blockDim.x)
+                raycaster_down_ray<BATCH>(a, base + le, r, pos, qr, seed, epoch, SCAN_STREAM_FLAGGED);
+        }
     }
     if (any && scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
 }

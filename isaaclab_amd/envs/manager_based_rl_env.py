@@ -41,6 +41,9 @@ class ManagerBasedRLEnv:
         # masked auto-reset: the stock event terms and the terrain curriculum ride in the reset branch of the post-physics
         # launch (False: one launch per term, as EventManager / CurriculumManager issue them)
         self.fold_events = os.environ.get("MDP_FOLD_EVENTS", "1") != "0"
+        # ... and the two launches behind it (flagged recast of the reset envs, the reference's conditional actuator step)
+        # are one when the actuator's gated launch can carry the recast (False: two launches, see concurrent_reset_tail)
+        self.fuse_reset_tail = os.environ.get("MDP_FUSE_RESET_TAIL", "1") != "0"
         self.post_reset_noalloc = False  # masked resets inside that launch: use the allocation-free entry point
         # extras["log"] of a masked reset: 0 = a fresh copy every step (the reference's dict of new tensors); R > 0 = the
         # launches publish into a ring of R buffers and extras["log"] holds views of them, valid for R - 1 further steps
@@ -471,7 +474,11 @@ class ManagerBasedRLEnv:
             # reference's post-reset write_data_to_sim (gate: log[0] = number of reset envs).  Neither reads what the
             # other writes (sensor buffers + scan columns / actuator state + joint efforts), and both are short chains of
             # dependent loads: on two streams (two branches of a captured hipGraph) they cost the longer one.
-            if self.concurrent_reset_tail and self.concurrent_post_physics:
+            arts = list(self.scene.articulations.values())
+            if self.fuse_reset_tail and len(arts) == 1 and not self.scene.rigid_objects and arts[0].can_carry_recast():
+                # ONE launch: recast blocks in front of the gated actuator blocks (mdp_actuator_lstm_compute_gated_with_recast)
+                self.scene.write_data_to_sim(gate=self._post_reset_log, recast=(cast, tm._dones_buf))
+            elif self.concurrent_reset_tail and self.concurrent_post_physics:
                 main = torch.cuda.current_stream(self.device)
                 side = self._side_stream
                 self._ev_scene.record(main)

@@ -38,14 +38,14 @@ class InteractiveScene:
             for entity in group.values():
                 entity.reset(env_ids)
 
-    def write_data_to_sim(self, joint_action=None, gate=None):
+    def write_data_to_sim(self, joint_action=None, gate=None, recast=None):
         """interactive_scene.py:484-494.  ``joint_action = (asset, L.MdpJointAction)``: that asset's actuator launch
         also processes the action of the step (``ActionManager.deferred_action``)."""
         for articulation in self.articulations.values():
             if joint_action is not None and articulation is joint_action[0]:
                 articulation.write_data_to_sim(joint_action=joint_action[1])
             else:
-                articulation.write_data_to_sim(gate=gate)
+                articulation.write_data_to_sim(gate=gate, recast=recast)
         for obj in self.rigid_objects.values():
             obj.write_data_to_sim()
 
