@@ -53,6 +53,10 @@ def parse():
                         " | h1_rough | shadow")
     p.add_argument("--ring", type=int, default=32,
                    help="env-steps in the replayed frame ring (x decimation frames); min(ring, steps) is used")
+    p.add_argument("--ring-mib", type=int, default=640,
+                   help="minimum size of the resident frame ring in MiB: the ring is `sets` x --ring env-steps of frames, one "
+                        "captured graph per set, replayed in rotation, so that a frame is read again only after > 2 x the "
+                        "256 MiB Infinity Cache of other frames (0: one set, the ring may then stay cache-resident)")
     p.add_argument("--regions", type=int, default=0,
                    help="how often the timed region of exactly --steps steps is repeated (median reported); 0 = auto:"
                         " at least 50 and about 2 s of timed work")
@@ -173,17 +177,24 @@ def main():
     ring = max(1, min(args.ring, K))
     tail = K % ring
     shadow = args.config == "shadow"
+    # Cold frames: `sets` segments of `ring` env-steps each, every segment with a graph of its own, replayed in rotation --
+    # between two reads of a frame lie sets x ring x decimation other frames, more than twice the 256 MiB Infinity Cache
+    # (MI355X_MICROARCH.md: FETCH_SIZE counts Infinity-Cache hits as well, so a ring that fits it is not "cold")
+    sets = 1
+    if args.ring_mib > 0 and not args.no_graph:
+        per_set = ring * frame_bytes_per_step(args)
+        sets = int(min(64, max(1, math.ceil(args.ring_mib * 2.0 ** 20 / per_set)), max(1, (4 << 30) // per_set)))
     if shadow:
         if args.auto_reset != "off" or args.events or args.normalize_obs:
             raise SystemExit("--auto-reset / --events / --normalize-obs belong to the velocity configs")
-        env, rec, actions = make_shadow_env(args, device, ring, seed=1234 + 1 + 1000 * rank)
+        env, rec, actions = make_shadow_env(args, device, ring * sets, seed=1234 + 1 + 1000 * rank)
         if world > 1:       # consecutive_successes (:424-431) is reduced over every rank's envs inside the step
             import torch.distributed as dist
 
             env.group = dist.group.WORLD
         stats = None
     else:
-        env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring, seed=1234 + 1 + 1000 * rank,
+        env, rec = make_velocity_env(args.config, num_envs=args.envs, device=device, steps=ring * sets, seed=1234 + 1 + 1000 * rank,
                                      small_terrain=args.small_terrain, inject_random=False, events=args.events)
         env._bench_config = args.config
         env.observation_manager.persistent_output = True
@@ -203,18 +214,21 @@ def main():
         actions = rec.actions.to(device)
         stats = EpisodeStats(env, world)
 
+    total = ring * sets                               # env-steps of frames resident in HBM
+    frames_per_step = env.physics.num_frames // total   # = decimation
+
     def eager_steps(k0, count):
         for k in range(k0, k0 + count):
-            env.step(actions[k % ring])
+            env.step(actions[k % total])
 
     # warm-up (also builds the term programs), W untimed steps
     warm = max(args.warmup, 1)
-    warm = (warm + ring - 1) // ring * ring       # keep the frame cursor aligned with the ring
+    warm = (warm + total - 1) // total * total    # keep the frame cursor aligned with the ring
     eager_steps(0, warm)
     torch.cuda.synchronize()
     _trace(rank, "warm-up done")
 
-    graph = tail_graph = None
+    graphs, tail_graph = [], None
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -223,25 +237,31 @@ def main():
                 eager_steps(0, ring)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: helper threads of the process group (watchdog, transport) may touch the runtime meanwhile
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                eager_steps(0, ring)
-            graph.replay()
-            torch.cuda.synchronize()
+            for s_ in range(sets):
+                env.physics._cursor = s_ * ring * frames_per_step     # this set's segment of the ring
+                g_ = torch.cuda.CUDAGraph()
+                # thread_local: helper threads of the process group (watchdog, transport) may touch the runtime meanwhile
+                with torch.cuda.graph(g_, capture_error_mode="thread_local"):
+                    eager_steps(s_ * ring, ring)
+                g_.replay()
+                torch.cuda.synchronize()
+                graphs.append(g_)
             if tail:
-                # the frame cursor is back at the start of the ring here: the tail graph replays its first `tail` steps
+                # the tail graph replays the first `tail` steps of the first segment
+                env.physics._cursor = 0
                 tail_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(tail_graph, capture_error_mode="thread_local"):
                     eager_steps(0, tail)
-                env.physics._cursor = 0            # capture moved the host cursor; replays do not depend on it
                 tail_graph.replay()
                 torch.cuda.synchronize()
+            env.physics._cursor = 0                # captures moved the host cursor; replays do not depend on it
         except Exception as e:  # capture is an optimisation; eager launches compute the same thing
             if rank == 0:
                 print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = tail_graph = None
+            graphs, tail_graph = [], None
             torch.cuda.synchronize()
+    graph = graphs[0] if graphs else None
+    next_set = [0]
 
     if stats is None:                   # Shadow hand: its one statistic (consecutive_successes) is reduced inside the step
         reduce_stats = lambda: None
@@ -256,7 +276,8 @@ def main():
         while done < k_steps:
             left = k_steps - done
             if graph is not None and left >= ring:
-                graph.replay()
+                graphs[next_set[0]].replay()       # the segments take turns: a frame is cold again when its turn comes
+                next_set[0] = (next_set[0] + 1) % len(graphs)
                 done += ring
                 replayed[0] += ring
             elif tail_graph is not None and left == tail:
@@ -264,7 +285,7 @@ def main():
                 done += tail
                 replayed[0] += tail
             else:
-                env.step(actions[done % ring])
+                env.step(actions[done % total])
                 done += 1
             if done >= next_stats:          # end of a rollout: merge the episode statistics across ranks
                 reduce_stats()
@@ -313,6 +334,24 @@ def main():
     times = times.cpu().numpy()
     elapsed = float(np.median(times))
     value = world * args.envs * K / elapsed
+    # Secondary figure, labelled as such: the same K steps replaying ONE segment over and over (what this bench timed up
+    # to round 2): its frames stay in the 256 MiB Infinity Cache, as state a simulator has just written would.
+    warm_ms = None
+    if len(graphs) > 1 and world == 1:
+        def warm_region():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            done = 0
+            while K - done >= ring:
+                graphs[0].replay()
+                done += ring
+            if tail_graph is not None and K - done == tail:
+                tail_graph.replay()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+
+        warm_region()
+        warm_ms = 1e3 * float(np.median([warm_region() for _ in range(min(len(times), 40))])) / (K - (0 if tail_graph is not None or tail == 0 else tail))
 
     out = None
     resets = None
@@ -331,9 +370,14 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": workload_text(env, args, ring),
+            "config": {"workload": workload_text(env, args, total),
                        "envs_per_gpu": args.envs, "hip_graph": graph is not None and replayed[0] == K,
                        "graph_replayed_steps": replayed[0], "graph_ring_steps": ring, "graph_tail_steps": tail,
+                       "graph_sets": len(graphs), "frame_ring_mib": env.physics.num_frames * frame_bytes(env) / 2.0 ** 20,
+                       # what the step reads of the ring between two visits of a frame (vs the 256 MiB Infinity Cache)
+                       "frame_ring_touched_mib": total * frame_bytes_per_step(args) / 2.0 ** 20,
+                       "frames_cold": bool(len(graphs) > 0 and total * frame_bytes_per_step(args) >= 2 * 256 * 2 ** 20),
+                       "ms_per_step_cache_resident_ring": warm_ms,
                        "timed_regions": int(len(times)), "region_ms_median": 1e3 * elapsed,
                        "region_ms_p10": 1e3 * float(np.percentile(times, 10)),
                        "region_ms_p90": 1e3 * float(np.percentile(times, 90)), "first_region_ms": 1e3 * first,
@@ -351,6 +395,25 @@ def main():
 
         dist.barrier()
         dist.destroy_process_group()
+
+
+def frame_bytes(env) -> int:
+    """Bytes of one synthetic physics frame resident in HBM."""
+    fr = env.physics._frames
+    return int(fr.shape[1] * fr.element_size())
+
+
+def frame_bytes_per_step(args) -> int:
+    """Frame bytes one env-step TOUCHES (decimation frames), from the robot's shape -- before the env exists.  A frame
+    also holds link states the velocity tasks never read; what competes for the Infinity Cache is what is read."""
+    # floats per env and frame: root transform 7 + root velocity 6 + 2 x joints + 3 x contact bodies (+ links for Shadow)
+    shapes = {"anymal_c_rough": (12, 17, 4), "anymal_d_rough": (12, 17, 4), "anymal_d_flat": (12, 17, 4),
+              "h1_rough": (19, 20, 4), "shadow": (24, 0, 2)}
+    j, b, dec = shapes.get(args.config, (12, 17, 4))
+    per_env = 13 + 2 * j + 3 * b
+    if args.config == "shadow":
+        per_env += 26 * 19 + 13 + 24 * 2       # link transforms / velocities / accelerations, object state, forces
+    return int(per_env * 4 * args.envs * dec)
 
 
 def workload_text(env, args, ring) -> str:
@@ -444,7 +507,8 @@ def measure_roofline_shadow(env, actions) -> dict:
     d = per_kernel[dom]
     total = shadow_algorithmic_bytes(env)
     return {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(d["kernel"]), "alg_bytes_per_launch": d["alg_bytes_per_env"] * N,
+            "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(d["kernel"]), "traffic_source": _pmc_traffic_source(),
+            "alg_bytes_per_launch": d["alg_bytes_per_env"] * N,
             "avg_launch_us": d["us"], "alg_bytes_per_env_step": total, "whole_step_us": 1e6 * step_s,
             "whole_step_GBps": total * N / step_s / 1e9, "kernels": per_kernel}
 
@@ -484,7 +548,8 @@ def cpu_baseline_shadow(rec, args) -> dict:
         O.full_observations(q, qd, lower, upper, obj, origins, in_hand, goal, body, fingers, a, cfg.vel_obs_scale)
     dt = time.perf_counter() - t0
     return {"value": n * steps / dt, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"{steps} env-steps x {n} envs of the same workload (numpy oracle, single thread), {dt:.1f} s"}
+            "sample": f"{steps} env-steps x {n} envs of the same workload (numpy oracle, single thread), {dt:.1f} s",
+            "reference_torch_cpu": reference_torch_cpu("shadow")}
 
 
 def _graph_time(fn, reps: int = 20, replays: int = 10) -> float:
@@ -526,6 +591,20 @@ def _pmc_traffic(kernel_fragment: str):
         if kernel_fragment in name and "FETCH_SIZE" in row and "WRITE_SIZE" in row:
             return (2.0 * row["FETCH_SIZE"] + row["WRITE_SIZE"]) * 1024.0
     return None
+
+
+def _pmc_traffic_source():
+    """Where `roofline.traffic` comes from: it is NOT measured by this run (counters need their own rocprofv3 --pmc
+    passes) but read from the committed table of the round's profile run; this names file, tag and commit."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        table = json.load(f)
+    src = dict(table.get("source", {}))
+    src["file"] = "profiles/pmc_traffic.json"
+    src["measured_in_this_run"] = False
+    return src
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # v_mfma_f32_16x16x4_f32, dense (MI355X_MICROARCH.md: equals the f32 vector peak)
@@ -636,8 +715,27 @@ def _roofline_summary(table, per_kernel, N) -> dict:
     total_alg = sum(b * l for b, l, _ in table.values())
     return {"bound": "hbm", "kernel": d["kernel"], "stage": dom, "achieved": d["GBps"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": d["GBps"] / HBM_PEAK_GBS, "traffic": _pmc_traffic(d["kernel"]),
+            "traffic_source": _pmc_traffic_source(),
             "alg_bytes_per_launch": d["alg_bytes_per_env"] * N, "avg_launch_us": d["us"],
             "alg_bytes_per_env_step": total_alg, "kernels": per_kernel}
+
+
+def reference_torch_cpu(config: str):
+    """The REFERENCE's own torch code for this path timed on CPU cores -- a stored figure, NOT measured by this run: it
+    was taken in the build container (the reference cannot travel to the GPU box), for the BASELINE.md configuration
+    that matches `config`; its ray cast is excluded (warp is not importable).  From profiles/r02_ref_cpu_baseline.json."""
+    path = os.path.join(ROOT, "profiles", "r02_ref_cpu_baseline.json")
+    row_of = {"anymal_d_flat": "C1", "anymal_d_rough": "C2", "anymal_c_rough": "C3", "h1_rough": "C4", "shadow": "C5"}
+    if config not in row_of or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        rows = json.load(f).get("rows", {})
+    r = rows.get(row_of[config])
+    if r is None:
+        return None
+    return {"value": r["env_steps_per_s"], "unit": "env-steps/s", "cores": r["cores"], "kind": "reference",
+            "row": row_of[config], "config": r["config"], "envs": r["envs"], "ray_cast": r["ray_cast"],
+            "measured_in_this_run": False, "source": "profiles/r02_ref_cpu_baseline.json (build container, torch CPU)"}
 
 
 def cpu_baseline(rec, args) -> dict:
@@ -656,7 +754,8 @@ def cpu_baseline(rec, args) -> dict:
     dt = time.perf_counter() - t0
     return {"value": rec.num_envs * steps / dt, "unit": "env-steps/s", "cores": threads, "kind": "port",
             "sample": f"{steps} env-steps x {rec.num_envs} envs of the same workload and frames (numpy oracle; ray cast in C/OpenMP"
-                      f" with {threads} threads, numpy part single-threaded), {dt:.1f} s"}
+                      f" with {threads} threads, numpy part single-threaded), {dt:.1f} s",
+            "reference_torch_cpu": reference_torch_cpu(args.config)}
 
 
 if __name__ == "__main__":
