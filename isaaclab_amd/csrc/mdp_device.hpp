@@ -85,6 +85,31 @@ MDP_DEV Q4 yaw_quat(Q4 q) {
     return normalize4(r, 1e-9f);
 }
 
+// The same quaternion without the three libm calls, for the one caller where they sit on a launch's critical path (the
+// per-env part of the height-scan cast: one lane computes it while the env's 187 ray lanes wait at a barrier, ~1.2 us of
+// a 12 us block life).  With (s, c) the reference's atan2 arguments and (sn, cn) = (s, c) / hypot(s, c) = (sin yaw, cos yaw):
+//   cn >= 0:  cos(yaw/2) = sqrt((1 + cn) / 2),  sin(yaw/2) = sn / (2 cos(yaw/2))
+//   cn <  0:  |sin(yaw/2)| = sqrt((1 - cn) / 2) with the sign of s (atan2's branch: -0 -> -pi),  cos(yaw/2) = sn / (2 sin(yaw/2))
+// -- no cancellation in either branch.  Evaluated in fp64 from the fp32 (s, c) the reference forms and rounded once: the
+// result is within half an fp32 ulp of the exact value for those arguments, i.e. closer to it than the reference's own
+// atan2 -> cos / sin chain (each step ~1 ulp), and within ~2e-7 of what torch returns.
+MDP_DEV Q4 yaw_quat_halfangle(Q4 q) {
+    const float s = 2.0f * (q.w * q.z + q.x * q.y), c = 1.0f - 2.0f * (q.y * q.y + q.z * q.z);
+    const double sd = (double)s, cd = (double)c;
+    const double r = sqrt(sd * sd + cd * cd);
+    if (!(r > 0.0)) return Q4{1.0f, 0.0f, 0.0f, 0.0f};       // atan2(0, 0) = 0
+    const double sn = sd / r, cn = cd / r;
+    double ch, sh;
+    if (cn >= 0.0) {
+        ch = sqrt(0.5 * (1.0 + cn));
+        sh = sn / (2.0 * ch);
+    } else {
+        sh = copysign(sqrt(0.5 * (1.0 - cn)), sd);
+        ch = sn / (2.0 * sh);
+    }
+    return normalize4(Q4{(float)ch, 0.0f, 0.0f, (float)sh}, 1e-9f);
+}
+
 // math.py:223-235
 MDP_DEV Q4 quat_conjugate(Q4 q) { return Q4{q.w, -q.x, -q.y, -q.z}; }
 

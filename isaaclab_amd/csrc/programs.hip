@@ -273,7 +273,7 @@ MDP_DEV void cast_pose(const mdp_raycaster_desc_t& d, int e, V3* pos, Q4* qr, Q4
     *pos = ld3(p);
     if (d.drift) { pos->x += d.drift[3 * e]; pos->y += d.drift[3 * e + 1]; pos->z += d.drift[3 * e + 2]; }
     *q = ld4(p + 3);
-    *qr = d.attach_yaw_only ? yaw_quat(*q) : *q;
+    *qr = d.attach_yaw_only ? yaw_quat_halfangle(*q) : *q;   // (one form for every path of the sensor)
 }
 
 MDP_DEV float obs_height_scan_cast(const RayAux& aux, float offset, int e, int k, bool od, const float* pose) {

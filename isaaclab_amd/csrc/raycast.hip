@@ -734,7 +734,7 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
             if (drift) { pos.x += drift[3 * e]; pos.y += drift[3 * e + 1]; pos.z += drift[3 * e + 2]; }
             // physics transforms are (x, y, z, w) (ray_caster.py:226-232 converts them); root_state rows are (w, x, y, z)
             Q4 q = pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
-            Q4 qr = yaw_only ? yaw_quat(q) : q;
+            Q4 qr = yaw_only ? yaw_quat_halfangle(q) : q;   // (one form for every path of the sensor)
             for (int r = lr; r < R; r += slot_w) {
                 V3 s = quat_apply(qr, ld3(starts_l + 3 * r));
                 s = V3{s.x + pos.x, s.y + pos.y, s.z + pos.z};

@@ -214,7 +214,7 @@ __device__ __forceinline__ void raycaster_env_bookkeeping(const RaycasterUpdateA
     se[5] = od ? 1.0f : 0.0f;
     if (od) {
         if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
-        Q4 qr = yaw_quat(q);
+        Q4 qr = yaw_quat_halfangle(q);     // (mdp_device.hpp: the libm-free form, this lane is the block's critical path)
 #ifdef MDP_STAMPS
         if (qr.w == 1.2345e30f) return;
         if (!a.stage) MDP_STAMP(6);
@@ -495,7 +495,7 @@ __device__ __forceinline__ void raycaster_update_flagged_blocks(const RaycasterU
             }
             if (od) {
                 if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
-                Q4 qr = yaw_quat(q);
+                Q4 qr = yaw_quat_halfangle(q);        // (the per-step cast's form: both give the same bits)
                 float* se = s_fenv[le];
                 se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
                 st3(a.pos_w + 3 * (int64_t)e, pos);
