@@ -42,32 +42,46 @@ __device__ __forceinline__ RootStateIn event_reset_root_state_load(const mdp_eve
     if (!a.injected_u && a.rng_state) { in.seed = a.rng_state[0]; in.epoch = a.rng_state[1 + e]; }
     return in;
 }
-// ... and the arithmetic + stores; org = the env's origin (env_origins row as the curriculum left it)
-__device__ __forceinline__ void event_reset_root_state_apply(const mdp_event_root_state_t& a, int e, const RootStateIn& in,
-                                                             V3 org) {
+// ... the draws and everything that does not need the env origin (a caller whose origin row is still in flight does this
+// meanwhile) ...
+struct RootStateDraw { float s[3]; Q4 q; float v[6]; };
+__device__ __forceinline__ RootStateDraw event_reset_root_state_draw(const mdp_event_root_state_t& a, int e, const RootStateIn& in) {
     if (!a.injected_u && a.rng_state) a.rng_state[1 + e] = in.epoch + 1;
     Uniforms u{a.injected_u, 12, in.seed, in.epoch, 0x45525354u, e};
     const float* d = in.d;
     float s[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) s[k] = u(k) * a.pose_scale[k] + a.pose_lo[k];
-    V3 pos{(d[0] + org.x) + s[0], (d[1] + org.y) + s[1], (d[2] + org.z) + s[2]};
-    Q4 q = quat_mul(Q4{d[3], d[4], d[5], d[6]}, quat_from_euler_xyz(s[3], s[4], s[5]));
-    float v[6];
+    RootStateDraw o;
+    o.s[0] = s[0]; o.s[1] = s[1]; o.s[2] = s[2];
+    o.q = quat_mul(Q4{d[3], d[4], d[5], d[6]}, quat_from_euler_xyz(s[3], s[4], s[5]));
 #pragma unroll
-    for (int k = 0; k < 6; ++k) v[k] = d[7 + k] + (u(6 + k) * a.vel_scale[k] + a.vel_lo[k]);
+    for (int k = 0; k < 6; ++k) o.v[k] = d[7 + k] + (u(6 + k) * a.vel_scale[k] + a.vel_lo[k]);
+    return o;
+}
+// ... and the position + stores; org = the env's origin (env_origins row as the curriculum left it)
+__device__ __forceinline__ void event_reset_root_state_finish(const mdp_event_root_state_t& a, int e, const RootStateIn& in,
+                                                              const RootStateDraw& w, V3 org) {
+    const float* d = in.d;
+    const V3 pos{(d[0] + org.x) + w.s[0], (d[1] + org.y) + w.s[1], (d[2] + org.z) + w.s[2]};
+    const Q4 q = w.q;
     float* r = a.root_state_w + (int64_t)e * 13;
     st3(r, pos);
     st4(r + 3, q);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) r[7 + k] = v[k];
+    for (int k = 0; k < 6; ++k) r[7 + k] = w.v[k];
     float* t = a.sim_root_transforms + (int64_t)e * 7;         // (x, y, z, qx, qy, qz, qw)
     st3(t, pos);
     t[3] = q.x; t[4] = q.y; t[5] = q.z; t[6] = q.w;
     float* sv = a.sim_root_velocities + (int64_t)e * 6;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) sv[k] = v[k];
+    for (int k = 0; k < 6; ++k) sv[k] = w.v[k];
     zero_body_acc(a.body_acc_w, a.num_bodies, e);
+}
+__device__ __forceinline__ void event_reset_root_state_apply(const mdp_event_root_state_t& a, int e, const RootStateIn& in,
+                                                             V3 org) {
+    const RootStateDraw w = event_reset_root_state_draw(a, e, in);
+    event_reset_root_state_finish(a, e, in, w, org);
 }
 __device__ __forceinline__ void event_reset_root_state_env(const mdp_event_root_state_t& a, int e) {
     const RootStateIn in = event_reset_root_state_load(a, e);
@@ -168,9 +182,9 @@ __device__ __forceinline__ TerrainLevelsIn terrain_levels_vel_load(int e, const 
     if (!a.injected_levels && a.rng_state) { in.seed = a.rng_state[0]; in.epoch = a.rng_state[1 + e]; }
     return in;
 }
-// ... and the decision, the level / origin stores; returns the new level, *org_out = the new origin
-__device__ __forceinline__ int64_t terrain_levels_vel_apply(int e, const mdp_curriculum_terrain_t& a, const TerrainLevelsIn& in,
-                                                            V3* org_out) {
+// ... the decision and the level store; returns the new level and REQUESTS its origin row (*org_out: in flight) ...
+__device__ __forceinline__ int64_t terrain_levels_vel_decide(int e, const mdp_curriculum_terrain_t& a, const TerrainLevelsIn& in,
+                                                             V3* org_out) {
     float distance = norm2(in.px - in.ox, in.py - in.oy);
     bool move_up = distance > a.half_tile_size;
     bool move_down = distance < (norm2(in.c0, in.c1) * a.max_episode_length_s) * 0.5f;
@@ -188,9 +202,17 @@ __device__ __forceinline__ int64_t terrain_levels_vel_apply(int e, const mdp_cur
         level = 0;
     }
     a.terrain_levels[e] = level;
-    const V3 o = ld3(a.terrain_origins + ((int64_t)level * a.num_cols + in.type) * 3);
-    st3(a.env_origins + 3 * (int64_t)e, o);
-    *org_out = o;
+    *org_out = ld3(a.terrain_origins + ((int64_t)level * a.num_cols + in.type) * 3);
+    return level;
+}
+// ... and the origin store (terrain_importer.py:307-324)
+__device__ __forceinline__ void terrain_levels_vel_commit(int e, const mdp_curriculum_terrain_t& a, V3 org) {
+    st3(a.env_origins + 3 * (int64_t)e, org);
+}
+__device__ __forceinline__ int64_t terrain_levels_vel_apply(int e, const mdp_curriculum_terrain_t& a, const TerrainLevelsIn& in,
+                                                            V3* org_out) {
+    const int64_t level = terrain_levels_vel_decide(e, a, in, org_out);
+    terrain_levels_vel_commit(e, a, *org_out);
     return level;
 }
 __device__ __forceinline__ int64_t terrain_levels_vel_env(int e, const mdp_curriculum_terrain_t& a) {

@@ -1208,8 +1208,14 @@ k_post_physics(PostArgs a) {
             if (mine && a.has_ev_root) rin = event_reset_root_state_load(a.ev_root, e);
             V3 org{0.0f, 0.0f, 0.0f};
             if (mine && a.has_ev_root && !a.has_cur) org = ld3(a.ev_root.env_origins + 3 * (int64_t)e);
+            // the new level's origin row is requested by the decision; the root-state event's draws (three Philox blocks,
+            // three sincos, a quaternion product: ~3 us of dependent arithmetic on one lane) run while it is in flight
+            int64_t lvl = lvl_old;
+            if (mine && a.has_cur) lvl = terrain_levels_vel_decide(e, a.cur, cin, &org);
+            RootStateDraw rdraw{};
+            if (mine && a.has_ev_root) rdraw = event_reset_root_state_draw(a.ev_root, e, rin);
+            if (mine && a.has_cur) terrain_levels_vel_commit(e, a.cur, org);
             if (a.has_cur) {
-                const int64_t lvl = mine ? terrain_levels_vel_apply(e, a.cur, cin, &org) : lvl_old;
                 double lv = e < N ? (double)lvl : 0.0;
                 for (int o = 32; o > 0; o >>= 1) lv += __shfl_xor(lv, o);
                 if (lane == 0)
@@ -1217,7 +1223,7 @@ k_post_physics(PostArgs a) {
                                        (unsigned long long)__double_as_longlong(lv), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             if (mine) {
-                if (a.has_ev_root) event_reset_root_state_apply(a.ev_root, e, rin, org);     // manager_based_rl_env.py:357-359
+                if (a.has_ev_root) event_reset_root_state_finish(a.ev_root, e, rin, rdraw, org);     // manager_based_rl_env.py:357-359
                 if (a.has_ev_mark) {
                     // (constant indices into the argument struct: a runtime index would move the whole struct to scratch)
 #pragma unroll

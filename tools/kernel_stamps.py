@@ -66,7 +66,7 @@ def cast_phases(st):
     d = np.diff(seq, axis=1)
     print("           cast phase medians (us): bookkeeping+barriers %.2f  pose+yaw %.2f  ray setup+cell walk %.2f  hit/obs stores %.2f"
           % tuple(np.median(d, axis=0)))
-    if os.environ.get("MDP_RC_STAGE", "1") != "0" and (r[:, 5] != 0).any():
+    if os.environ.get("MDP_RC_STAGE", "0") != "0" and (r[:, 5] != 0).any():
         # staged walk: 5 = every ray's list is in the table (first barrier), 6 = records staged (second barrier)
         fine = np.diff(r[:, [3, 5, 6, 4]] / 100.0, axis=1)
         print("           staged walk (us): cell + patch lookups, table %.2f  -> cooperative record fetch %.2f  -> walk out of LDS %.2f"
