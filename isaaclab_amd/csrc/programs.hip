@@ -1032,16 +1032,20 @@ __device__ __forceinline__ void post_observations(const PostArgs& a, const mdp_t
 #ifndef MDP_POST_MIN_WAVES_ROLES
 #define MDP_POST_MIN_WAVES_ROLES 4
 #endif
-template <int BATCH, bool RESET, bool STAGED, bool ROLES>
+// ONE: the cast blocks are one env each with one ray per lane (raycaster_update_down_block_one)
+template <int BATCH, bool RESET, bool STAGED, bool ROLES, bool ONE = false>
 __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAVES_RESET
                                                         : (ROLES ? MDP_POST_MIN_WAVES_ROLES : MDP_POST_MIN_WAVES))
 k_post_physics(PostArgs a) {
     static_assert(!(RESET && ROLES), "the reset branch orders rewards -> reset -> observations");
+    static_assert(!(ONE && (STAGED || ROLES)), "one-env cast blocks: the per-ray walk, launches with a cast");
     extern __shared__ __align__(16) unsigned char s_dyn[];
     if (blockIdx.x >= a.nb_post) {
         MDP_STAMP(0, 1);
         if constexpr (STAGED)
             raycaster_update_down_blocks_staged(a.cast, a.cast_epb, a.cast_slot_w, blockIdx.x - a.nb_post, a.nb_cast, s_dyn);
+        else if constexpr (ONE)
+            raycaster_update_down_block_one<BATCH>(a.cast, blockIdx.x - a.nb_post);
         else
             raycaster_update_down_blocks<BATCH>(a.cast, a.cast_epb, a.cast_slot_w, blockIdx.x - a.nb_post, a.nb_cast);
         MDP_STAMP(1);
@@ -1686,6 +1690,7 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
     if (threads_env <= 0 && cast && cast->num_rays > 0 && cast->num_rays < 256)
         threads = (((256 / cast->num_rays) * cast->num_rays + 63) / 64) * 64;   // 187 rays -> 192 threads
     // ---- cast
+    bool cast_one = false;
     if (cast) {
         MDP_REQUIRE(cast->mesh && cast->root_pose && cast->ray_starts_local && cast->ray_dirs_local && cast->pos_w &&
                         cast->quat_w && cast->ray_hits_w && cast->num_rays > 0, "cast: null pointer");
@@ -1744,6 +1749,9 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
             return c > 0 ? c : (int64_t)(1 << 20);
         }();
         a.nb_cast = (unsigned)std::min<int64_t>(((int64_t)num_envs + a.cast_epb - 1) / a.cast_epb, cast_cap);
+        // one env per block, one ray per lane, a block per env: the loop-free cast routine (MDP_POST_CAST_ONE=0: the general one)
+        static const bool one_env = [] { const char* v = std::getenv("MDP_POST_CAST_ONE"); return !v || std::atoi(v) != 0; }();
+        cast_one = one_env && a.cast_epb == 1 && cast->num_rays <= threads && a.nb_cast == (unsigned)num_envs;
     }
     // ---- scene update
     if (update) {
@@ -1880,11 +1888,14 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         // Enqueued here, behind every argument check, so a rejected call leaves nothing in the stream / a capture
         if (clear_ticket) MDP_CHECK_HIP(hipMemsetAsync(a.log_sums, 0, sizeof(double), as_stream(stream)));
         pose_pass();
+        // (the reset instantiation keeps the general cast routine: its launch is bound by the blocks with done envs,
+        // one-env cast blocks change nothing measurable there -- 111.6 vs 111.3 us/step)
         hipLaunchKernelGGL((k_post_physics<1, true, false, false>), grid, dim3(threads), lds, as_stream(stream), a);
     } else {
         pose_pass();
         if (staged) hipLaunchKernelGGL((k_post_physics<1, false, true, false>), grid, dim3(threads), lds, as_stream(stream), a);
         else if (a.obs_waves > 0) hipLaunchKernelGGL((k_post_physics<1, false, false, true>), grid, dim3(threads), lds, as_stream(stream), a);
+        else if (cast_one) hipLaunchKernelGGL((k_post_physics<1, false, false, false, true>), grid, dim3(threads), lds, as_stream(stream), a);
         else hipLaunchKernelGGL((k_post_physics<1, false, false, false>), grid, dim3(threads), lds, as_stream(stream), a);
     }
     MDP_LAUNCH_CHECK();

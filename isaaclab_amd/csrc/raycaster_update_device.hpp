@@ -398,6 +398,43 @@ __device__ __forceinline__ void raycaster_update_down_blocks(const RaycasterUpda
     if (scan.obs && scan.rng && threadIdx.x == 0) scan.rng[1 + block] = epoch + 1;
 }
 
+// The same for the launch shape of the 4096-env step: ONE env per block, one ray per lane (R <= blockDim.x, as many
+// blocks as envs).  No env / ray loops, no lane -> (env slot, ray) division, the env index is the block's: the per-env
+// addresses are wave-uniform and the routine needs a handful of vector registers less than the general one above --
+// which is what keeps the post-physics kernel's 80-register instantiation out of scratch.  Same statements per ray.
+template <int BATCH>
+__device__ __forceinline__ void raycaster_update_down_block_one(const RaycasterUpdateArgs& a, unsigned block) {
+    __shared__ float s_env1[6];   // pos.xyz, yaw quaternion (w, z), cast flag
+    const int R = a.R;
+    const int e = (int)block;
+    const int r = (int)threadIdx.x;
+    const mdp_height_scan_obs_t& scan = a.scan;
+    uint64_t seed = 0, epoch = 0;
+    if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + block]; }
+    float sv[6] = {0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+    if (a.pose_ready) {
+        const float4* w = reinterpret_cast<const float4*>(a.pose_ws + 8 * (int64_t)e);
+        const float4 w0 = w[0], w1 = w[1];
+        sv[0] = w0.x; sv[1] = w0.y; sv[2] = w0.z; sv[3] = w0.w; sv[4] = w1.x; sv[5] = w1.y;
+    } else {
+        if (r == 0) raycaster_env_bookkeeping(a, e, s_env1);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 6; ++k) sv[k] = s_env1[k];
+    }
+    MDP_STAMP(2);
+    const bool od = sv[5] != 0.0f;
+    if (r < R) {
+        if (od) {
+            MDP_STAMP(3);
+            raycaster_down_ray<BATCH>(a, e, r, V3{sv[0], sv[1], sv[2]}, Q4{sv[3], 0.0f, 0.0f, sv[4]}, seed, epoch);
+        } else if (scan.obs) {
+            scan_store(scan, e, r, R, a.pos_w[3 * (int64_t)e + 2], a.hits[((int64_t)e * R + r) * 3 + 2], seed, epoch);
+        }
+    }
+    if (scan.obs && scan.rng && r == 0) scan.rng[1 + block] = epoch + 1;
+}
+
 // The same block routine with the staged walk (the host sets a.stage, picks the kernel instantiation that calls this
 // one and provides rc_stage_lds_bytes() of dynamic LDS at `stage_lds`, 16-byte aligned; meshes with non-finite
 // vertices are not staged).  A function of its own: the per-ray routine above stays exactly as it was measured.
