@@ -972,8 +972,9 @@ int mdp_actuator_lstm_compute_gated(const float* gate, const mdp_net_desc_t* des
                                     float* applied_effort, void* stream);
 /* mdp_raycaster_update_flagged(reset_mask) and mdp_actuator_lstm_compute_gated(gate) -- the two launches that follow a
  * post-physics launch with masked resets (sensor_base.py:182-195 + ray_caster.py:220-260 for the reset envs;
- * manager_based_rl_env.py:214-222) -- as ONE launch: recast blocks in front, actuator blocks behind; the whole launch
- * does nothing unless *gate > 0 (no env was reset: nothing to cast again either).  Covers the register-resident LSTM
+ * manager_based_rl_env.py:214-222) -- as ONE launch: recast blocks in front, actuator blocks behind.  The actuator
+ * blocks do nothing unless *gate > 0; the recast blocks follow reset_mask / is_outdated exactly like
+ * mdp_raycaster_update_flagged (no env reset and none outdated: nothing is cast).  Covers the register-resident LSTM
  * (hidden 8, <= 2 layers, linear decoder) and a cast that mdp_raycaster_update_flagged accepts, else
  * MDP_ERR_UNSUPPORTED -- callers then issue the two launches. */
 int mdp_actuator_lstm_compute_gated_with_recast(const float* gate, const mdp_net_desc_t* desc, const float* packed_weights,

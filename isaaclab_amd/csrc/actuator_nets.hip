@@ -321,15 +321,18 @@ k_lstm8_reg(RaycasterUpdateArgs cast, unsigned nb_cast, mdp_scene_update_t upd, 
             const float* __restrict__ eff_lim, const float* __restrict__ vel_lim, float sat,
             float* __restrict__ computed, float* __restrict__ applied, const float* __restrict__ gate) {
     constexpr int H = 8, TPL = 2;
-    if (gate != nullptr && *gate <= 0.0f) return;      // mdp_actuator_lstm_compute_gated: nothing happens this launch
-    // the carried scene update takes the FIRST blocks of the grid: its chain of dependent loads starts with the launch
-    // instead of behind the actuator blocks
+    // (recast blocks do not wait for the gate: their own flags decide, as in mdp_raycaster_update_flagged -- with no env
+    // reset there is none to cast -- and the gate word would be one more round trip at the head of the launch's longest
+    // chain)
     if (RECAST) {
         if (blockIdx.x < nb_cast) {
             raycaster_update_flagged_blocks<2>(cast, blockIdx.x);
             return;
         }
     }
+    if (gate != nullptr && *gate <= 0.0f) return;      // mdp_actuator_lstm_compute_gated: nothing happens this launch
+    // the carried scene update takes the FIRST blocks of the grid: its chain of dependent loads starts with the launch
+    // instead of behind the actuator blocks
     const unsigned nb_upd = RECAST ? nb_cast : gridDim.x - nb_act;
     if (!RECAST && blockIdx.x < nb_upd) {
         MDP_STAMP(0, 1);

@@ -1750,7 +1750,8 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         }();
         a.nb_cast = (unsigned)std::min<int64_t>(((int64_t)num_envs + a.cast_epb - 1) / a.cast_epb, cast_cap);
         // one env per block, one ray per lane, a block per env: the loop-free cast routine (MDP_POST_CAST_ONE=0: the general one)
-        static const bool one_env = [] { const char* v = std::getenv("MDP_POST_CAST_ONE"); return !v || std::atoi(v) != 0; }();
+        const char* one_v = std::getenv("MDP_POST_CAST_ONE");   // read at every call, like MDP_RC_STAGE
+        const bool one_env = !one_v || std::atoi(one_v) != 0;
         cast_one = one_env && a.cast_epb == 1 && cast->num_rays <= threads && a.nb_cast == (unsigned)num_envs;
     }
     // ---- scene update

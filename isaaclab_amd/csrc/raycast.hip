@@ -767,11 +767,13 @@ __global__ void k_raycaster_update(mdp_mesh_view_t mesh, int N, int R, int epb, 
 #ifndef MDP_RCD_MIN_WAVES
 #define MDP_RCD_MIN_WAVES 1
 #endif
-template <int BATCH, bool STAGED>
+// ONE: a block per env, a lane per ray (raycaster_update_down_block_one: the loop-free routine)
+template <int BATCH, bool STAGED, bool ONE = false>
 __global__ void __launch_bounds__(256, MDP_RCD_MIN_WAVES)
 k_raycaster_update_down(RaycasterUpdateArgs a, int epb, int slot_w) {
     extern __shared__ __align__(16) unsigned char s_stage[];
     if constexpr (STAGED) raycaster_update_down_blocks_staged(a, epb, slot_w, blockIdx.x, gridDim.x, s_stage);
+    else if constexpr (ONE) raycaster_update_down_block_one<BATCH>(a, blockIdx.x);
     else raycaster_update_down_blocks<BATCH>(a, epb, slot_w, blockIdx.x, gridDim.x);
 }
 
@@ -909,6 +911,8 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
             int64_t c = b ? std::atoll(b) : 0;
             return c > 0 ? c : (int64_t)(1 << 20);
         }();
+        const char* one_v = std::getenv("MDP_RC_ONE");        // (0: the general routine for every launch shape)
+        const bool one_env = !one_v || std::atoi(one_v) != 0;
         const char* stage_v = std::getenv("MDP_RC_STAGE");    // read at every call: tests flip it inside one process
         const int stage_env = stage_v ? std::atoi(stage_v) : 0;
         RaycasterUpdateArgs ra;
@@ -931,6 +935,9 @@ extern "C" int mdp_raycaster_update(const mdp_mesh_t* mesh, int num_envs, int nu
         if (ra.stage)
             hipLaunchKernelGGL((k_raycaster_update_down<1, true>), dim3(grid_for(blocks, 1, block_cap)), dim3(threads),
                                stage_lds, as_stream(stream), ra, epb, slot_w);
+        else if (batch == 1 && one_env && epb == 1 && num_rays <= threads && blocks <= block_cap)
+            hipLaunchKernelGGL((k_raycaster_update_down<1, false, true>), dim3((unsigned)blocks), dim3(threads), 0, as_stream(stream),
+                               ra, epb, slot_w);
         else if (batch == 1) RCD_LAUNCH(1); else if (batch == 2) RCD_LAUNCH(2); else if (batch == 3) RCD_LAUNCH(3); else RCD_LAUNCH(4);
 #undef RCD_LAUNCH
         MDP_LAUNCH_CHECK();

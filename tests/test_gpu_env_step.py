@@ -98,6 +98,27 @@ def test_staged_cast_in_the_post_physics_launch(device, monkeypatch):
     assert np.isfinite(runs[0][1]).all()
 
 
+def test_one_env_cast_blocks_in_the_post_physics_launch(device, monkeypatch):
+    """The post-physics launch's cast blocks take the loop-free routine when a block owns one env with one ray per lane
+    (`raycaster_update_down_block_one`, instantiation `k_post_physics<.., ONE>`); MDP_POST_CAST_ONE=0 keeps the general
+    routine.  Same statements per ray: the step's outputs, the sensor's hit points and its bookkeeping are bit-identical
+    (203 envs: a ragged last manager block; update period > 0 so that some steps do not cast)."""
+    runs = []
+    for one in ("1", "0"):
+        monkeypatch.setenv("MDP_POST_CAST_ONE", one)
+        env, rec, outs = run_env("anymal_c_rough", 203, 5, device, seed=15, small_terrain=True, persistent=True,
+                                 scan_in_cast=True, mesh_accel="grid")
+        assert getattr(env, "_single_launch_steps", 0) == 4
+        sensor = env.scene["height_scanner"]
+        runs.append((outs, to_np(sensor.data.ray_hits_w), to_np(sensor.data.pos_w), to_np(sensor._timestamp)))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    for k in (1, 2, 3):
+        np.testing.assert_array_equal(runs[0][k], runs[1][k])
+    assert np.isfinite(runs[0][1]).all()
+
+
 @pytest.mark.parametrize("n,fuse_cast,fused,persistent,scan_in_cast,single_launch",
                          ((5, False, True, False, True, True), (128, False, True, True, True, False),
                           (128, True, True, False, True, True), (37, False, False, False, True, True),

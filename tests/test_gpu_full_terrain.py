@@ -200,6 +200,48 @@ def test_full_terrain_staged_cast_equals_per_ray_walk(device, full_terrain, monk
         assert np.isfinite(got[0]).all(-1).mean() > 0.8 and (got[0] != -7.0).all()
 
 
+def test_full_terrain_one_env_blocks_equal_general_routine(device, full_terrain, monkeypatch):
+    """The loop-free routine for one env per block / one ray per lane (`raycaster_update_down_block_one`, the default for
+    187-ray patterns) against the general block routine (MDP_RC_ONE=0) through `mdp_raycaster_update` with the sensor's
+    bookkeeping on: all 765,952 rays of 4096 envs on the full terrain, a third of the envs not outdated (they keep their
+    hits): hit points, sensor pose buffers, timestamps and flags bit for bit."""
+    import torch
+
+    from isaaclab_amd import _lib as L
+    from oracle import mdp_np as P
+
+    terrain, mesh, soup, caster = full_terrain
+    n = 4096
+    starts, dirs = P.grid_pattern(0.1, [1.6, 1.0])
+    starts = starts + np.array([0, 0, 20.0], np.float32)
+    R = starts.shape[0]
+    d_starts, d_dirs = to_dev(starts, device), to_dev(dirs, device)
+    pose, _ = _poses(terrain, n, seed=29)
+    d_pose = to_dev(pose, device)
+    rng = np.random.default_rng(5)
+    ts0 = rng.uniform(0.0, 1.0, n).astype(np.float32)
+    last0 = (ts0 - rng.uniform(0.0, 0.04, n)).astype(np.float32)      # update period 0.02: about half are due
+    flag0 = (rng.uniform(size=n) < 0.2).astype(np.uint8)
+    drift = rng.uniform(-0.05, 0.05, (n, 3)).astype(np.float32)
+    got = []
+    for one in ("1", "0"):
+        monkeypatch.setenv("MDP_RC_ONE", one)
+        pos_w, quat_w = torch.zeros(n, 3, device=device), torch.zeros(n, 4, device=device)
+        hits = torch.full((n, R, 3), -7.0, device=device)
+        ts, last, flag = to_dev(ts0, device), to_dev(last0, device), to_dev(flag0, device)
+        d_drift = to_dev(drift, device)
+        L.check(L.lib.mdp_raycaster_update(mesh.handle, n, R, d_pose.data_ptr(), 7, d_drift.data_ptr(), d_starts.data_ptr(),
+                                           d_dirs.data_ptr(), 1, 1, 1e6, pos_w.data_ptr(), quat_w.data_ptr(),
+                                           hits.data_ptr(), ts.data_ptr(), last.data_ptr(), flag.data_ptr(), None, 0,
+                                           0.005, 0.02, L.stream(device)))
+        torch.cuda.synchronize()
+        got.append([to_np(x) for x in (hits, pos_w, quat_w, ts, last, flag)])
+    for x, y in zip(*got):
+        np.testing.assert_array_equal(x, y)
+    cast = (got[0][0] != -7.0).all((1, 2))
+    assert 0.3 < cast.mean() < 0.95          # both kinds of env are in the comparison
+
+
 def test_full_terrain_env_step_slice_vs_oracle(device, full_terrain):
     """The benchmark's env step (Anymal-C rough, 4096 envs, five launches incl. mdp_post_physics_step with its cast
     blocks) on the FULL terrain, three steps: an env slice replayed by the oracle on the same frames -- observations incl.
