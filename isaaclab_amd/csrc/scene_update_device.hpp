@@ -466,6 +466,24 @@ __device__ __forceinline__ void scene_update_carried(const mdp_scene_update_t& d
     if (carried_envs > 0) {
         int64_t e0 = (int64_t)b * carried_envs;
         int64_t e1 = e0 + carried_envs < d.num_envs ? e0 + carried_envs : d.num_envs;
+#ifndef MDP_UPD_CARRIED_TWO_PHASE
+        int widest = 13;
+        if (d.num_joints > widest) widest = d.num_joints;
+        if (d.num_contact_bodies > widest) widest = d.num_contact_bodies;
+        if (widest * carried_envs <= (int)blockDim.x) {
+            // One round of items: requests -> barrier -> results AND the per-env words together.  The barrier sits where
+            // the loads have arrived (a body thread's read of its env's timestamps must not see the env thread's
+            // rewrite of them), not behind the result stores: scene_update_envs' barrier also waits for every result
+            // store to be acknowledged, a round trip at the tail of the launch's longest blocks.
+            SceneUpdateSlice us;
+            scene_update_slice_request(d, (int)e0, (int)e1, us);
+            asm volatile("" ::"v"(us.ts), "v"(us.tl), "v"((int)us.flag), "v"(us.ets), "v"(us.etl), "v"((int)us.eflag));
+            __syncthreads();
+            scene_update_slice_store(d, dt, us);
+            scene_update_slice_commit(d, dt, (int)e0, us);
+            return;
+        }
+#endif
         scene_update_envs(d, dt, (int)e0, (int)e1);
     } else {
         scene_update_block(d, dt, b, nb_root, nb_joint, nb_contact);
