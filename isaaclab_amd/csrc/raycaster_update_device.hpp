@@ -227,6 +227,52 @@ __device__ __forceinline__ void raycaster_env_bookkeeping(const RaycasterUpdateA
     }
 }
 
+// raycaster_env_bookkeeping with its global stores held back (RcBook) until the caller commits them: in a block whose
+// ray lanes wait at a barrier for this lane, stores in front of the barrier make the barrier wait for their
+// acknowledgements as well.
+struct RcBook { V3 pos; Q4 q; float t_now; bool ticked, cast; };
+__device__ __forceinline__ void raycaster_env_bookkeeping_deferred(const RaycasterUpdateArgs& a, int e, float* se, RcBook& bk) {
+    const float* p = a.pose + (int64_t)e * a.ld_pose;
+    const uint8_t od_in = a.outdated ? a.outdated[e] : (uint8_t)1;
+    const float ts_in = a.ts ? a.ts[e] : 0.0f;
+    const float last_in = (a.tick_dt > 0.0f) ? a.ts_last[e] : 0.0f;
+    V3 pos = ld3(p);
+    const Q4 q = a.pose_xyzw ? Q4{p[6], p[3], p[4], p[5]} : ld4(p + 3);
+    V3 dr{0.0f, 0.0f, 0.0f};
+    if (a.drift) dr = ld3(a.drift + 3 * (int64_t)e);
+    bool od = od_in != 0;
+    float t_now = ts_in;
+#ifdef MDP_STAMPS
+    if (pos.x == 1.2345e30f && dr.x == 1.0f && ts_in == last_in) return;   // waits for every input
+    MDP_STAMP(5);
+#endif
+    bk.ticked = a.tick_dt > 0.0f;
+    if (bk.ticked) {
+        t_now += a.tick_dt;
+        if ((t_now - last_in) + 1e-6f >= a.period) od = true;
+    }
+    se[5] = od ? 1.0f : 0.0f;
+    if (od) {
+        if (a.drift) { pos.x += dr.x; pos.y += dr.y; pos.z += dr.z; }
+        Q4 qr = yaw_quat_halfangle(q);
+#ifdef MDP_STAMPS
+        if (qr.w == 1.2345e30f) return;
+        MDP_STAMP(6);
+#endif
+        se[0] = pos.x; se[1] = pos.y; se[2] = pos.z; se[3] = qr.w; se[4] = qr.z;
+    }
+    bk.pos = pos; bk.q = q; bk.t_now = t_now; bk.cast = od;
+}
+__device__ __forceinline__ void raycaster_env_bookkeeping_commit(const RaycasterUpdateArgs& a, int e, const RcBook& bk) {
+    if (bk.ticked) a.ts[e] = bk.t_now;
+    if (bk.cast) {
+        st3(a.pos_w + 3 * (int64_t)e, bk.pos);
+        st4(a.quat_w + 4 * (int64_t)e, bk.q);
+        if (a.ts_last) a.ts_last[e] = bk.t_now;
+        if (a.outdated) a.outdated[e] = 0;
+    }
+}
+
 // The same for every env in a pass of its own (one thread per env) in front of a launch with many envs: the results go
 // to pose_ws (N, 8) and the cast blocks of that launch start with their rays (RaycasterUpdateArgs::pose_ready).
 __device__ __forceinline__ void raycaster_pose_pass(const RaycasterUpdateArgs& a) {
@@ -412,12 +458,15 @@ __device__ __forceinline__ void raycaster_update_down_block_one(const RaycasterU
     uint64_t seed = 0, epoch = 0;
     if (scan.obs && scan.rng) { seed = scan.rng[0]; epoch = scan.rng[1 + block]; }
     float sv[6] = {0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f};
+    RcBook bk{};
     if (a.pose_ready) {
         const float4* w = reinterpret_cast<const float4*>(a.pose_ws + 8 * (int64_t)e);
         const float4 w0 = w[0], w1 = w[1];
         sv[0] = w0.x; sv[1] = w0.y; sv[2] = w0.z; sv[3] = w0.w; sv[4] = w1.x; sv[5] = w1.y;
     } else {
-        if (r == 0) raycaster_env_bookkeeping(a, e, s_env1);
+        // (lane 0's stores to the sensor's buffers go out at the END of the routine: in front of the barrier the barrier
+        // would wait for their acknowledgements, right behind it the lane's own ray would)
+        if (r == 0) raycaster_env_bookkeeping_deferred(a, e, s_env1, bk);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 6; ++k) sv[k] = s_env1[k];
@@ -432,6 +481,7 @@ __device__ __forceinline__ void raycaster_update_down_block_one(const RaycasterU
             scan_store(scan, e, r, R, a.pos_w[3 * (int64_t)e + 2], a.hits[((int64_t)e * R + r) * 3 + 2], seed, epoch);
         }
     }
+    if (!a.pose_ready && r == 0) raycaster_env_bookkeeping_commit(a, e, bk);
     if (scan.obs && scan.rng && r == 0) scan.rng[1 + block] = epoch + 1;
 }
 
