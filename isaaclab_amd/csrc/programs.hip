@@ -1092,7 +1092,7 @@ k_post_physics(PostArgs a) {
         for (int i = threadIdx.x; i < a.num_fills * FW; i += blockDim.x) df[i] = sf[i];
     }
     // ---- scene.update(physics_dt) for this block's envs (interactive_scene.py:496-513)
-    if (a.has_upd) scene_update_envs(a.upd, a.physics_dt, e0, e1);
+    if (a.has_upd) scene_update_envs(a.upd, a.physics_dt, e0, e1, true);
     MDP_STAMP(1);
     const int e = lane < E ? e0 + lane : N;   // lanes beyond the block's envs idle through the term phases
     // (reset branch with a terrain curriculum: the levels of ALL the block's envs go into the statistics; requested here,

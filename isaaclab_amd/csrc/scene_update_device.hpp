@@ -130,7 +130,12 @@ __device__ __forceinline__ void scene_update_block(const mdp_scene_update_t& d, 
 // need (sources, previous velocities, bookkeeping words, force, history rows, timers) before it waits for any of it, so
 // a round costs about two memory round trips instead of a dozen chained ones -- the block is one link of a long chain
 // of dependent phases, and every round trip is paid in full.
-__device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, float dt, int e0, int e1) {
+// barrier_first: the block barrier that separates the body threads' reads of the per-env words from the env threads'
+// rewrite of them sits in the LAST round, where that round's loads have arrived, instead of behind the loop -- the
+// results of the last round and the per-env words then go out together and the barrier does not wait for result stores
+// to be acknowledged (callers whose next phase starts with a barrier of its own: the post-physics manager blocks).
+__device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, float dt, int e0, int e1,
+                                                  const bool barrier_first = false) {
     constexpr int TICKS = (int)(sizeof(d.tick_timestamp) / sizeof(d.tick_timestamp[0]));
     constexpr int HMAX = 4;  // history rows prefetched into registers; longer histories take the in-place shift
     const int n = e1 - e0;
@@ -208,6 +213,10 @@ __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, f
                 if (d.current_air_time) { ca = d.current_air_time[ci]; cc = d.current_contact_time[ci]; }
             }
         }
+        if (barrier_first && base + (int)blockDim.x >= rounds_items) {      // (block-uniform)
+            asm volatile("" ::"v"(ts), "v"(tl), "v"((int)flag), "v"(bts), "v"(btl), "v"((int)bflag));
+            __syncthreads();
+        }
         // ---- results
         if (hr) d.root_state_w[ro] = rv;
         if (hj) {
@@ -250,7 +259,7 @@ __device__ __forceinline__ void scene_update_envs(const mdp_scene_update_t& d, f
             }
         }
     }
-    __syncthreads();
+    if (!barrier_first || rounds_items <= 0) __syncthreads();
     if (has_contact && he) {
         float t_new = bts + dt;
         bool od = (bflag != 0) || ((t_new - btl) + 1e-6f >= d.contact_update_period);
