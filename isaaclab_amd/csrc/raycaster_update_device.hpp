@@ -452,7 +452,29 @@ template <int BATCH>
 __device__ __forceinline__ void raycaster_update_down_block_one(const RaycasterUpdateArgs& a, unsigned block) {
     __shared__ float s_env1[6];   // pos.xyz, yaw quaternion (w, z), cast flag
     const int R = a.R;
-    const int e = (int)block;
+    // XCD-aware env order.  The launch's blocks are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, each
+    // XCD has its own L2), so with env = block the envs e .. e + 7 -- neighbours in every per-env array (pose rows,
+    // time stamps, flags: several envs per 64-byte sector) -- are fetched into eight L2s.  Blocks of one residue class
+    // take RUNS of 2^MDP_CAST_XCD_RUN consecutive envs instead, the runs dealt round-robin (a bijection of [0, N) whenever
+    // 8 << RUN divides N; affinity only, nothing depends on where a block runs; the first 8 << RUN blocks still cover the
+    // first 8 << RUN envs, so the launch keeps its env order at that grain).  Measured at 4096 envs (exp51): runs of
+    // 8 / 16 / 32 / 64 envs: post-physics launch 29.55 -> 29.3 / 28.95 / 29.1 / 29.7 us.  MDP_CAST_XCD_ORDER=1, each XCD
+    // one contiguous EIGHTH of the envs, is 11 us SLOWER (40.8 us): TerrainImporter maps consecutive envs to the same
+    // terrain column, a column is one terrain type, and an XCD that draws the stair columns casts for 40 us while the
+    // XCDs with the height-field columns idle -- blocks are dealt to XCDs statically, the launch ends with its slowest XCD.
+#ifndef MDP_CAST_XCD_ORDER
+#define MDP_CAST_XCD_ORDER 2
+#endif
+#ifndef MDP_CAST_XCD_RUN
+#define MDP_CAST_XCD_RUN 4
+#endif
+    const unsigned nenv = (unsigned)a.N;
+    int e = (int)block;
+    if (MDP_CAST_XCD_ORDER == 1 && (nenv & 7u) == 0) e = (int)((block & 7u) * (nenv >> 3) + (block >> 3));
+    if (MDP_CAST_XCD_ORDER == 2 && (nenv & ((8u << MDP_CAST_XCD_RUN) - 1u)) == 0) {
+        const unsigned k = block >> 3;
+        e = (int)(((k >> MDP_CAST_XCD_RUN) << (MDP_CAST_XCD_RUN + 3)) + ((block & 7u) << MDP_CAST_XCD_RUN) + (k & ((1u << MDP_CAST_XCD_RUN) - 1u)));
+    }
     const int r = (int)threadIdx.x;
     const mdp_height_scan_obs_t& scan = a.scan;
     uint64_t seed = 0, epoch = 0;
