@@ -930,6 +930,12 @@ struct PostArgs {
 #ifndef MDP_POST_MAX_THREADS
 #define MDP_POST_MAX_THREADS 768
 #endif
+// launches with at least this many envs take the DENSE instantiation (MDP_POST_DENSE_ENVS overrides, 0 = never)
+static int64_t post_dense_envs() {
+    const char* v = std::getenv("MDP_POST_DENSE_ENVS");   // read at every call, like the other A/B knobs
+    const int64_t n = v ? std::atoll(v) : 12288;
+    return n > 0 ? n : INT64_MAX;
+}
 // per-env part of the ray caster's update for every env, in front of k_post_physics when the launch has many envs
 __global__ void __launch_bounds__(256) k_cast_pose(RaycasterUpdateArgs a) { raycaster_pose_pass(a); }
 
@@ -1033,10 +1039,20 @@ __device__ __forceinline__ void post_observations(const PostArgs& a, const mdp_t
 #define MDP_POST_MIN_WAVES_ROLES 4
 #endif
 // ONE: the cast blocks are one env each with one ray per lane (raycaster_update_down_block_one)
-template <int BATCH, bool RESET, bool STAGED, bool ROLES, bool ONE = false>
+// DENSE: the ONE instantiation with a register budget for MDP_POST_MIN_WAVES_DENSE waves per SIMD, for launches of many
+// rounds of cast blocks (>= MDP_POST_DENSE_ENVS envs): there the launch is the cast's throughput = resident cast blocks
+// / block life, the manager chain (which pays for the smaller budget with 56 B of scratch per lane) is hidden behind it.
+// Same-box A/B (exp54): 16,384 envs post-physics 77.4 -> 71.9 us, step 181.3 -> 178.3 us; 65,536 envs 302 -> 288 us,
+// step 598.7 -> 585.8 us; 8 waves the same or worse; at 8192 envs (H1) and below 6 waves stay faster.
+#ifndef MDP_POST_MIN_WAVES_DENSE
+#define MDP_POST_MIN_WAVES_DENSE 7
+#endif
+template <int BATCH, bool RESET, bool STAGED, bool ROLES, bool ONE = false, bool DENSE = false>
 __global__ void __launch_bounds__(MDP_POST_MAX_THREADS, RESET ? MDP_POST_MIN_WAVES_RESET
-                                                        : (ROLES ? MDP_POST_MIN_WAVES_ROLES : MDP_POST_MIN_WAVES))
+                                                        : (ROLES ? MDP_POST_MIN_WAVES_ROLES
+                                                                 : (DENSE ? MDP_POST_MIN_WAVES_DENSE : MDP_POST_MIN_WAVES)))
 k_post_physics(PostArgs a) {
+    static_assert(!DENSE || ONE, "the dense register budget is an instantiation of the one-env cast launch");
     static_assert(!(RESET && ROLES), "the reset branch orders rewards -> reset -> observations");
     static_assert(!(ONE && (STAGED || ROLES)), "one-env cast blocks: the per-ray walk, launches with a cast");
     extern __shared__ __align__(16) unsigned char s_dyn[];
@@ -1896,6 +1912,7 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         pose_pass();
         if (staged) hipLaunchKernelGGL((k_post_physics<1, false, true, false>), grid, dim3(threads), lds, as_stream(stream), a);
         else if (a.obs_waves > 0) hipLaunchKernelGGL((k_post_physics<1, false, false, true>), grid, dim3(threads), lds, as_stream(stream), a);
+        else if (cast_one && num_envs >= post_dense_envs()) hipLaunchKernelGGL((k_post_physics<1, false, false, false, true, true>), grid, dim3(threads), lds, as_stream(stream), a);
         else if (cast_one) hipLaunchKernelGGL((k_post_physics<1, false, false, false, true>), grid, dim3(threads), lds, as_stream(stream), a);
         else hipLaunchKernelGGL((k_post_physics<1, false, false, false>), grid, dim3(threads), lds, as_stream(stream), a);
     }
