@@ -40,8 +40,29 @@ struct NetLayout {
     int mlp_w[MAX_MLP_LAYERS];  // [((tin * 4 + r) * MLP_NT + tout) * 64] (first layer after an LSTM: [(s * MLP_NT + tout) * 64])
     int mlp_b[MAX_MLP_LAYERS];  // [(tout * 4 + r) * 64]
     int mlp_ksteps[MAX_MLP_LAYERS];
-    int total;
+    int total;         // floats of the fragment tables above (what the LDS kernels stage)
+    int reg8;          // k_lstm8_reg's copy of its fragments, four per lane and load (reg8_sources), or -1
+    int total_all;     // size of the blob: total + the reg8 section
 };
+
+// Networks k_lstm8_reg takes (the ANYdrive shape): hidden 8, <= 2 layers, Linear(8 -> 1) decoder.
+bool reg8_shape(const mdp_net_desc_t& d) { return d.lstm_layers >= 1 && d.lstm_layers <= 2 && d.lstm_hidden == 8 && d.mlp_layers == 1; }
+// The fragments a lane of k_lstm8_reg holds, in the order it unpacks them: per layer the weight fragments (k-step major)
+// and the eight bias fragments, then the decoder's two weight and four bias fragments.  src[i] = offset of fragment i in
+// the tables above; returns their number (a multiple of 4: 20 for one layer, 36 for two).
+int reg8_sources(const mdp_net_desc_t& d, const NetLayout& L, int* src) {
+    constexpr int TPL = 2;
+    int n = 0;
+    for (int l = 0; l < d.lstm_layers; ++l) {
+        const int nk = (l == 0 ? 1 : TPL) + TPL;
+        for (int k = 0; k < nk; ++k)
+            for (int t = 0; t < TPL; ++t) src[n++] = L.lstm_w[l] + (k * TPL + t) * 64;
+        for (int i = 0; i < 4 * TPL; ++i) src[n++] = L.lstm_b[l] + i * 64;
+    }
+    for (int s2 = 0; s2 < TPL; ++s2) src[n++] = L.mlp_w[0] + (s2 * 2) * 64;   // (s * MLP_NT) * 64, tile 0
+    for (int r = 0; r < 4; ++r) src[n++] = L.mlp_b[0] + r * 64;
+    return n;
+}
 
 int tiles_for(int width) { return (width + 15) / 16; }
 
@@ -67,6 +88,13 @@ int make_layout(const mdp_net_desc_t& d, NetLayout& L) {
         off += MLP_NT * 4 * 64;
     }
     L.total = off;
+    L.reg8 = -1;
+    if (reg8_shape(d) && d.lstm_input <= 4) {
+        int src[40];
+        L.reg8 = off;
+        off += reg8_sources(d, L, src) * 64;
+    }
+    L.total_all = off;
     return off;
 }
 
@@ -384,24 +412,38 @@ k_lstm8_reg(RaycasterUpdateArgs cast, unsigned nb_cast, mdp_scene_update_t upd, 
     };
     int64_t g = wave;
     if (g < ngroups) load_group(g);
-    // weight / bias fragments of this lane (layer 0 has one input k-step, deeper layers TPL)
-    float w[NL][2 * TPL * TPL], bias[NL][4 * TPL], wm[TPL], bm[4];
+    // weight / bias fragments of this lane (layer 0 has one input k-step, deeper layers TPL): NF numbers, read four at
+    // a time from the blob's reg8 section (mdp_net_pack lays them out per lane in exactly this order) -- 9 vector-memory
+    // instructions instead of 36: the launch's busiest unit is the texture-address path, ~15 cycles per wave and
+    // memory instruction whatever its width (TA_TA_BUSY / TA_TOTAL_WAVEFRONTS), and these loads were 60 % of them
+    constexpr int NF = NL == 2 ? 36 : 20;
+    float frag[NF];
+    {
+        const float4* p8 = reinterpret_cast<const float4*>(packed + net.L.reg8) + lane;
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const float* pw = packed + net.L.lstm_w[l];
-        const int nk = (l == 0 ? 1 : TPL) + TPL;
-#pragma unroll
-        for (int k = 0; k < 2 * TPL; ++k)
-#pragma unroll
-            for (int t = 0; t < TPL; ++t) w[l][k * TPL + t] = k < nk ? pw[(k * TPL + t) * 64 + lane] : 0.0f;
-        const float* pb = packed + net.L.lstm_b[l];
-#pragma unroll
-        for (int i = 0; i < 4 * TPL; ++i) bias[l][i] = pb[i * 64 + lane];
+        for (int g4 = 0; g4 < NF / 4; ++g4) {
+            const float4 v = p8[g4 * 64];
+            frag[4 * g4] = v.x; frag[4 * g4 + 1] = v.y; frag[4 * g4 + 2] = v.z; frag[4 * g4 + 3] = v.w;
+        }
     }
+    float w[NL][2 * TPL * TPL], bias[NL][4 * TPL], wm[TPL], bm[4];
+    {
+        int fi = 0;
 #pragma unroll
-    for (int s = 0; s < TPL; ++s) wm[s] = packed[net.L.mlp_w[0] + (s * MLP_NT) * 64 + lane];
+        for (int l = 0; l < NL; ++l) {
+            const int nk = (l == 0 ? 1 : TPL) + TPL;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bm[r] = packed[net.L.mlp_b[0] + r * 64 + lane];
+            for (int k = 0; k < 2 * TPL; ++k)
+#pragma unroll
+                for (int t = 0; t < TPL; ++t) w[l][k * TPL + t] = k < nk ? frag[fi++] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4 * TPL; ++i) bias[l][i] = frag[fi++];
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < TPL; ++s2) wm[s2] = frag[fi++];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bm[r] = frag[fi++];
+    }
     const int act = net.d.mlp_act[0];
     if (has_slice) scene_update_slice_store(upd, dt, us);
     while (g < ngroups) {
@@ -613,6 +655,12 @@ extern "C" int mdp_net_pack(const mdp_net_desc_t* desc, const float* const* weig
                     out[L.mlp_b[l] + (t * 4 + r) * 64 + lane] = o < out_dim ? b[o] : 0.0f;
                 }
     }
+    if (L.reg8 >= 0) {      // the same numbers once more, four fragments of a lane side by side: one 16-byte load each
+        int src[40];
+        const int n = reg8_sources(d, L, src);
+        for (int i = 0; i < n; ++i)
+            for (int lane = 0; lane < 64; ++lane) out[L.reg8 + ((i / 4) * 64 + lane) * 4 + (i % 4)] = out[src[i] + lane];
+    }
     return MDP_OK;
 }
 
@@ -696,7 +744,7 @@ static int lstm_launch(const mdp_joint_action_t* action, const mdp_scene_update_
     } while (0)
     // register-resident weights for the ANYdrive shape (MDP_LSTM_GENERIC=1 forces the LDS kernel: parity tests)
     static const bool force_generic = [] { const char* e = std::getenv("MDP_LSTM_GENERIC"); return e && e[0] == '1'; }();
-    if (!force_generic && desc->lstm_hidden == 8 && desc->lstm_layers <= 2 && desc->mlp_layers == 1 && rows < (1ll << 31)) {
+    if (!force_generic && net.L.reg8 >= 0 && rows < (1ll << 31)) {
         RaycasterUpdateArgs no_cast;
         std::memset(&no_cast, 0, sizeof(no_cast));
 #define L8(NLAYERS)                                                                                                 \
