@@ -97,3 +97,55 @@ def test_product_path_has_no_cpu_fallback():
             if fn.endswith(".py"):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, fn)
+
+
+def test_net_pack_fragment_tables_and_register_kernel_section():
+    """mdp_net_pack is host code (no GPU): for the ANYdrive shape (LSTM(2, 8, 2) + Linear(8, 1)) the blob holds the
+    MFMA fragment tables and, behind them, the register kernel's section -- the same numbers, four fragments of a lane
+    side by side in the order the kernel unpacks them (per layer: weight fragments k-step major, eight bias fragments;
+    then the decoder's two weight and four bias fragments).  Other shapes have no such section."""
+    import numpy as np
+
+    def pack(hidden, layers):
+        rng = np.random.default_rng(3)
+        desc = L.MdpNetDesc()
+        desc.lstm_layers, desc.lstm_hidden, desc.lstm_input, desc.mlp_layers = layers, hidden, 2, 1
+        desc.mlp_dims[0], desc.mlp_dims[1] = hidden, 1
+        arrs = []
+        for l in range(layers):
+            d_in = 2 if l == 0 else hidden
+            arrs += [rng.standard_normal((4 * hidden, d_in)), rng.standard_normal((4 * hidden, hidden)),
+                     rng.standard_normal(4 * hidden), rng.standard_normal(4 * hidden)]
+        arrs += [rng.standard_normal((1, hidden)), rng.standard_normal(1)]
+        arrs = [np.ascontiguousarray(a, dtype=np.float32) for a in arrs]
+        size = L.lib.mdp_net_packed_size(C.byref(desc))
+        assert size > 0
+        out = np.full(size, np.nan, dtype=np.float32)
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        L.check(L.lib.mdp_net_pack(C.byref(desc), C.byref(ptrs), out.ctypes.data))
+        assert np.isfinite(out).all()
+        return out
+
+    tpl = 2
+    for layers, n_frag in ((1, 20), (2, 36)):
+        out = pack(8, layers)
+        tables = sum(((1 if l == 0 else tpl) + tpl) * tpl * 64 + 4 * tpl * 64 for l in range(layers)) + tpl * 2 * 64 + 2 * 4 * 64
+        assert out.size == tables + n_frag * 64
+        src, off = [], 0
+        for l in range(layers):
+            nk = (1 if l == 0 else tpl) + tpl
+            src += [off + (k * tpl + t) * 64 for k in range(nk) for t in range(tpl)]
+            off += nk * tpl * 64
+            src += [off + i * 64 for i in range(4 * tpl)]
+            off += 4 * tpl * 64
+        src += [off + (s * 2) * 64 for s in range(tpl)]
+        off += tpl * 2 * 64
+        src += [off + r * 64 for r in range(4)]
+        assert len(src) == n_frag
+        sec = out[tables:].reshape(n_frag // 4, 64, 4)
+        for i, o in enumerate(src):
+            np.testing.assert_array_equal(sec[i // 4, :, i % 4], out[o:o + 64])
+    # hidden 16: fragment tables only (LDS kernel)
+    out16 = pack(16, 1)
+    tpl16 = 4
+    assert out16.size == (1 + tpl16) * tpl16 * 64 + 4 * tpl16 * 64 + tpl16 * 2 * 64 + 2 * 4 * 64
