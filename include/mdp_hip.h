@@ -94,7 +94,9 @@ typedef struct {
     int32_t mlp_act[8];    /* activation after layer i (last one normally 0) */
 } mdp_net_desc_t;
 
-/* size in floats of the packed blob for `desc` */
+/* size in floats of the packed blob for `desc` (the fragment tables; for the ANYdrive shape -- hidden 8,
+ * <= 2 layers, Linear decoder -- followed by the same fragments laid out four per lane for the
+ * register-resident kernel).  The blob is opaque to the caller: upload it 16-byte aligned, pass it back. */
 int64_t mdp_net_packed_size(const mdp_net_desc_t* desc);
 /* weights: host array of pointers in PyTorch state_dict order:
  * for each LSTM layer l: weight_ih_l (4H,in), weight_hh_l (4H,H), bias_ih_l (4H), bias_hh_l (4H);
