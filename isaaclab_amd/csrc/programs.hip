@@ -1905,9 +1905,16 @@ static int post_physics_launch(int num_envs, const mdp_scene_update_t* update, f
         // Enqueued here, behind every argument check, so a rejected call leaves nothing in the stream / a capture
         if (clear_ticket) MDP_CHECK_HIP(hipMemsetAsync(a.log_sums, 0, sizeof(double), as_stream(stream)));
         pose_pass();
-        // (the reset instantiation keeps the general cast routine: its launch is bound by the blocks with done envs,
-        // one-env cast blocks change nothing measurable there -- 111.6 vs 111.3 us/step)
-        hipLaunchKernelGGL((k_post_physics<1, true, false, false>), grid, dim3(threads), lds, as_stream(stream), a);
+        // (one-env cast blocks in the reset instantiation too: its launch is bound by the blocks with done envs, so they
+        // are worth little there -- 109.8 -> 109.3 us/step with events, exp56; MDP_POST_RESET_ONE=0: the general routine.
+        // 6 waves per SIMD for this instantiation stay slower, with either routine: 111.4 / 109.9)
+        {
+            const char* ro = std::getenv("MDP_POST_RESET_ONE");     // A/B knob, read at every call
+            if (cast_one && !(ro && std::atoi(ro) == 0))
+                hipLaunchKernelGGL((k_post_physics<1, true, false, false, true>), grid, dim3(threads), lds, as_stream(stream), a);
+            else
+                hipLaunchKernelGGL((k_post_physics<1, true, false, false>), grid, dim3(threads), lds, as_stream(stream), a);
+        }
     } else {
         pose_pass();
         if (staged) hipLaunchKernelGGL((k_post_physics<1, false, true, false>), grid, dim3(threads), lds, as_stream(stream), a);
