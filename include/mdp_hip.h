@@ -754,6 +754,21 @@ int mdp_stats_masked_sums(const float* values, int rows, int num_envs, const uin
  * levels: `Curriculum/terrain_levels` = mean over ALL envs, TASKS/.../velocity/mdp/curriculums.py:55, mask NULL). */
 int mdp_stats_masked_sums_typed(const void* values, int elem_kind, int rows, int num_envs, const uint8_t* mask,
                                 double* out, void* stream);
+/* All of a rollout's statistics families in ONE launch: source i is a (rows_i, N) block of element kind elem_kind_i
+ * (as above), summed over the mask when `masked` is non-zero and over all envs otherwise; out receives the
+ * [sum, count] pairs of the sources' rows back to back, i.e. exactly what one mdp_stats_masked_sums_typed call per
+ * source writes (same order of additions: bit-identical) -- the packed vector of EpisodeStats
+ * (reward_manager.py:115-121, command_manager.py:136-142, termination_manager.py:142-144, curriculums.py:55). */
+#define MDP_STATS_MAX_SOURCES 8
+typedef struct {
+    const void* values;   /* (rows, N) row-major */
+    int32_t elem_kind;    /* 0 float, 1 uint8, 2 int64 */
+    int32_t rows;
+    int32_t masked;       /* != 0: follows `mask` */
+    int32_t _pad;
+} mdp_stats_source_t;
+int mdp_stats_masked_sums_multi(const mdp_stats_source_t* sources, int num_sources, int num_envs, const uint8_t* mask,
+                                double* out, void* stream);
 
 /* Reset of per-env state by MASK instead of by id list, many buffers in ONE launch (the `buf[env_ids] = value` lines of
  * ManagerBasedRLEnv._reset_idx's callees: sensor_base.py:192-195, contact_sensor.py:143-155, action_manager.py reset,

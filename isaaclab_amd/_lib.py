@@ -144,6 +144,12 @@ class MdpJointAction(C.Structure):
     ]
 
 
+class MdpStatsSource(C.Structure):
+    """Mirror of ``mdp_stats_source_t``."""
+
+    _fields_ = [("values", C.c_void_p), ("elem_kind", C.c_int32), ("rows", C.c_int32), ("masked", C.c_int32), ("_pad", C.c_int32)]
+
+
 class MdpFill(C.Structure):
     """Mirror of ``mdp_fill_t``."""
 
@@ -355,6 +361,8 @@ _HDR = os.path.join(os.path.dirname(_HERE), "include", "mdp_hip.h")
 MATH_OPS = _parse_enum(_HDR, "MDP_MATH_")
 ACT_KINDS = _parse_enum(_HDR, "MDP_ACT_")
 PROG_OBS, PROG_REWARD, PROG_TERMINATION = 0, 1, 2
+with open(_HDR) as _f:
+    MDP_STATS_MAX_SOURCES = int(re.search(r"#define\s+MDP_STATS_MAX_SOURCES\s+(\d+)", _f.read()).group(1))
 
 
 def exported_symbols() -> list[str]:

@@ -4,6 +4,7 @@
 // LAB/managers/reward_manager.py:115-121, termination_manager.py:142-144, command_manager.py:136-142.
 #include "mdp_device.hpp"
 #include "mdp_host.hpp"
+#include <cstring>
 
 using namespace mdp;
 
@@ -78,6 +79,55 @@ __global__ void k_masked_sums(const T* __restrict__ v, int rows, int N, const ui
         __syncthreads();
     }
     if (threadIdx.x == 0) { out[2 * k] = rs[0]; out[2 * k + 1] = rc[0]; }
+}
+
+// The same for several (K_i, N) blocks of different element types in ONE launch (mdp_stats_masked_sums_multi): block b
+// finds its source and row from the table's running row count; the per-row routine, its order of additions and so its
+// sums are k_masked_sums' own.
+struct StatSources { mdp_stats_source_t s[MDP_STATS_MAX_SOURCES]; int n; };
+
+template <typename T>
+__device__ __forceinline__ void masked_sums_row(const T* __restrict__ row, int N, const uint8_t* __restrict__ mask,
+                                                double* __restrict__ out2) {
+    __shared__ double rs[256];
+    __shared__ double rc[256];
+    double s = 0.0, c = 0.0;
+    for (int e0 = threadIdx.x; e0 < N; e0 += 8 * blockDim.x) {
+        T x[8];
+        uint8_t m[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int e = e0 + j * blockDim.x;
+            const bool in = e < N;
+            x[j] = in ? row[e] : (T)0;
+            m[j] = in ? (mask ? mask[e] : (uint8_t)1) : (uint8_t)0;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            s += m[j] ? (double)x[j] : 0.0;
+            c += m[j] ? 1.0 : 0.0;
+        }
+    }
+    rs[threadIdx.x] = s;
+    rc[threadIdx.x] = c;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) { rs[threadIdx.x] += rs[threadIdx.x + off]; rc[threadIdx.x] += rc[threadIdx.x + off]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = rs[0]; out2[1] = rc[0]; }
+}
+
+__global__ void __launch_bounds__(256) k_masked_sums_multi(StatSources t, int N, const uint8_t* __restrict__ mask,
+                                                            double* __restrict__ out) {
+    int k = blockIdx.x, i = 0;
+    while (i < t.n - 1 && k >= t.s[i].rows) { k -= t.s[i].rows; ++i; }     // (block-uniform)
+    const mdp_stats_source_t src = t.s[i];
+    const uint8_t* m = src.masked ? mask : nullptr;
+    double* o = out + 2 * (int64_t)blockIdx.x;
+    if (src.elem_kind == 0) masked_sums_row(reinterpret_cast<const float*>(src.values) + (int64_t)k * N, N, m, o);
+    else if (src.elem_kind == 1) masked_sums_row(reinterpret_cast<const uint8_t*>(src.values) + (int64_t)k * N, N, m, o);
+    else masked_sums_row(reinterpret_cast<const int64_t*>(src.values) + (int64_t)k * N, N, m, o);
 }
 
 struct FillTable { mdp_fill_t f[MDP_MAX_FILLS]; };
@@ -364,6 +414,31 @@ extern "C" int mdp_stats_masked_sums_typed(const void* values, int elem_kind, in
         hipLaunchKernelGGL(k_masked_sums<uint8_t>, dim3(rows), dim3(256), 0, st, (const uint8_t*)values, rows, num_envs, mask, out);
     else
         hipLaunchKernelGGL(k_masked_sums<int64_t>, dim3(rows), dim3(256), 0, st, (const int64_t*)values, rows, num_envs, mask, out);
+    MDP_LAUNCH_CHECK();
+    return MDP_OK;
+}
+
+extern "C" int mdp_stats_masked_sums_multi(const mdp_stats_source_t* sources, int num_sources, int num_envs,
+                                           const uint8_t* mask, double* out, void* stream) {
+    MDP_REQUIRE(sources && out, "null pointer");
+    MDP_REQUIRE(num_sources >= 0 && num_sources <= MDP_STATS_MAX_SOURCES, "at most %d sources (got %d)", MDP_STATS_MAX_SOURCES,
+                num_sources);
+    StatSources t;
+    std::memset(&t, 0, sizeof(t));
+    int64_t rows = 0;
+    for (int i = 0; i < num_sources; ++i) {
+        const mdp_stats_source_t& s = sources[i];
+        MDP_REQUIRE(s.elem_kind >= 0 && s.elem_kind <= 2, "source %d: unknown element kind %d", i, s.elem_kind);
+        MDP_REQUIRE(s.rows >= 0, "source %d: negative row count", i);
+        if (s.rows == 0) continue;
+        MDP_REQUIRE(s.values, "source %d: null pointer", i);
+        MDP_REQUIRE(!s.masked || mask, "source %d follows the mask, but mask is NULL", i);
+        t.s[t.n++] = s;
+        rows += s.rows;
+    }
+    if (rows == 0) return MDP_OK;
+    MDP_REQUIRE(rows < (1 << 30), "too many rows");
+    hipLaunchKernelGGL(k_masked_sums_multi, dim3((unsigned)rows), dim3(256), 0, as_stream(stream), t, num_envs, mask, out);
     MDP_LAUNCH_CHECK();
     return MDP_OK;
 }

@@ -150,12 +150,25 @@ class EpisodeStats:
             self.names.append("Curriculum/terrain_levels")
             self._sources.append((levels, 1, self.I64, False))
         self.payload = torch.zeros(2 * len(self.names), dtype=torch.float64, device=self.device)
+        self._table = None          # mdp_stats_source_t records of _sources (the buffers are persistent)
+        self._separate = os.environ.get("MDP_STATS_SEPARATE") == "1"   # A/B knob: one launch per family, side stream even alone
         self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._work = None
         self._ready = torch.cuda.Event() if self._stream is not None else None
 
     def fill(self, out: torch.Tensor, mask: torch.Tensor | None, stream) -> None:
-        """This rank's ``[sum, count]`` pairs into ``out`` (2 * len(names) doubles), launches on ``stream``."""
+        """This rank's ``[sum, count]`` pairs into ``out`` (2 * len(names) doubles): ONE launch on ``stream`` for all
+        families (``mdp_stats_masked_sums_multi``; one ``mdp_stats_masked_sums_typed`` launch per family when there are
+        more families than its table holds -- the same sums either way)."""
+        if (not self._separate and len(self._sources) <= L.MDP_STATS_MAX_SOURCES
+                and (mask is not None or not any(m for *_, m in self._sources))):
+            if self._table is None:
+                self._table = (L.MdpStatsSource * len(self._sources))()
+                for t, (src, rows, kind, masked) in zip(self._table, self._sources):
+                    t.values, t.elem_kind, t.rows, t.masked = src.data_ptr(), kind, rows, int(masked)
+            L.check(L.lib.mdp_stats_masked_sums_multi(self._table, len(self._sources), self.env.num_envs, L.ptr(mask),
+                                                      out.data_ptr(), stream))
+            return
         off = 0
         for src, rows, kind, masked in self._sources:
             L.check(L.lib.mdp_stats_masked_sums_typed(src.data_ptr(), kind, rows, self.env.num_envs,
@@ -170,7 +183,13 @@ class EpisodeStats:
             work.wait()
 
     def reduce_async(self, mask: torch.Tensor | None = None, force_collective: bool = False):
-        """Per-rank partial sums on a side stream, then one all-reduce(sum) of the packed vector."""
+        """Per-rank partial sums on a side stream, then one all-reduce(sum) of the packed vector.  With one rank there is
+        no collective to overlap: the sums go to the CURRENT stream, in order behind the step (a hop to the side stream
+        and back costs more than the launch -- ~25 us of cross-queue signalling on this stack)."""
+        if self.world <= 1 and not force_collective and not self._separate:
+            self.fill(self.payload, mask, L.stream(self.device))
+            self._work = None
+            return
         cur = torch.cuda.current_stream(self.device)
         self._ready.record(cur)
         with torch.cuda.stream(self._stream):

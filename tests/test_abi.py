@@ -54,7 +54,7 @@ def test_struct_mirrors_match_header():
              ("mdp_event_push_t", L.MdpEventPush), ("mdp_curriculum_terrain_t", L.MdpCurriculumTerrain), ("mdp_obs_normalize_t", L.MdpObsNormalize), ("mdp_imu_args_t", L.MdpImuArgs), ("mdp_frame_transformer_args_t", L.MdpFrameTransformerArgs),
              ("mdp_raycaster_camera_args_t", L.MdpRaycasterCameraArgs), ("mdp_event_reset_mark_t", L.MdpEventResetMark),
              ("mdp_inhand_goal_reset_t", L.MdpInhandGoalReset), ("mdp_inhand_obs_args_t", L.MdpInhandObsArgs),
-             ("mdp_inhand_reset_t", L.MdpInhandReset)]
+             ("mdp_inhand_reset_t", L.MdpInhandReset), ("mdp_stats_source_t", L.MdpStatsSource)]
     sizes = _c_sizeof([p[0] for p in pairs])
     for (name, cls), sz in zip(pairs, sizes):
         assert C.sizeof(cls) == sz, f"{name}: header {sz} bytes, ctypes mirror {C.sizeof(cls)}"

@@ -259,6 +259,46 @@ def test_stats_kernels(device):
     assert np.all(o[:, 1] == mask.sum())
 
 
+def test_masked_sums_of_every_family_in_one_launch(device):
+    """mdp_stats_masked_sums_multi == one mdp_stats_masked_sums_typed call per family, bit for bit (float rows, uint8
+    done flags, int64 levels over ALL envs), and equal to numpy; bad arguments are rejected before any launch."""
+    import torch
+
+    from isaaclab_amd import _lib as L
+
+    rng = np.random.RandomState(11)
+    for n in (1, 1000, 4096):
+        fam = [((rng.randn(10, n) * 5).astype(np.float32), 0, True), (rng.randn(1, n).astype(np.float32), 0, True),
+               ((rng.rand(2, n) < 0.4).astype(np.uint8), 1, True), (rng.randint(0, 10, (1, n)).astype(np.int64), 2, False)]
+        mask = rng.rand(n) < 0.3
+        d_mask = to_dev(mask, device)
+        dev = [to_dev(v, device) for v, _, _ in fam]
+        rows = sum(v.shape[0] for v, _, _ in fam)
+        one = torch.full((2 * rows,), float("nan"), dtype=torch.float64, device=device)
+        off = 0
+        for d, (v, kind, masked) in zip(dev, fam):
+            L.check(L.lib.mdp_stats_masked_sums_typed(L.ptr(d), kind, v.shape[0], n, L.ptr(d_mask) if masked else None,
+                                                      one[off:].data_ptr(), L.stream()))
+            off += 2 * v.shape[0]
+        table = (L.MdpStatsSource * len(fam))()
+        for t, d, (v, kind, masked) in zip(table, dev, fam):
+            t.values, t.elem_kind, t.rows, t.masked = d.data_ptr(), kind, v.shape[0], int(masked)
+        multi = torch.full((2 * rows,), float("nan"), dtype=torch.float64, device=device)
+        L.check(L.lib.mdp_stats_masked_sums_multi(table, len(fam), n, L.ptr(d_mask), L.ptr(multi), L.stream()))
+        np.testing.assert_array_equal(to_np(multi), to_np(one))
+        o, k = to_np(multi).reshape(rows, 2), 0
+        for v, kind, masked in fam:
+            sel = mask if masked else np.ones(n, dtype=bool)
+            for r in range(v.shape[0]):
+                np.testing.assert_allclose(o[k, 0], v[r].astype(np.float64)[sel].sum(), rtol=1e-12, atol=1e-9)
+                assert o[k, 1] == sel.sum()
+                k += 1
+    with pytest.raises(ValueError):      # a masked family without a mask
+        L.check(L.lib.mdp_stats_masked_sums_multi(table, len(fam), n, None, L.ptr(multi), L.stream()))
+    with pytest.raises(ValueError):
+        L.check(L.lib.mdp_stats_masked_sums_multi(table, L.MDP_STATS_MAX_SOURCES + 1, n, L.ptr(d_mask), L.ptr(multi), L.stream()))
+
+
 def test_masked_fill(device):
     """mdp_masked_fill == ``buf[env_ids] = value`` for every buffer of the call: env-major (N, k) float / int64 / bool
     buffers, a term-major (k, N) block, untouched rows bit-identical; empty mask = no-op; too many buffers = ValueError."""
