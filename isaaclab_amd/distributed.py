@@ -150,7 +150,7 @@ class EpisodeStats:
             self.names.append("Curriculum/terrain_levels")
             self._sources.append((levels, 1, self.I64, False))
         self.payload = torch.zeros(2 * len(self.names), dtype=torch.float64, device=self.device)
-        self._table = None          # mdp_stats_source_t records of _sources (the buffers are persistent)
+        self._table = {}            # mdp_stats_source_t records of _sources, with / without a mask (the buffers are persistent)
         self._separate = os.environ.get("MDP_STATS_SEPARATE") == "1"   # A/B knob: one launch per family, side stream even alone
         self._stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         self._work = None
@@ -160,13 +160,14 @@ class EpisodeStats:
         """This rank's ``[sum, count]`` pairs into ``out`` (2 * len(names) doubles): ONE launch on ``stream`` for all
         families (``mdp_stats_masked_sums_multi``; one ``mdp_stats_masked_sums_typed`` launch per family when there are
         more families than its table holds -- the same sums either way)."""
-        if (not self._separate and len(self._sources) <= L.MDP_STATS_MAX_SOURCES
-                and (mask is not None or not any(m for *_, m in self._sources))):
-            if self._table is None:
-                self._table = (L.MdpStatsSource * len(self._sources))()
-                for t, (src, rows, kind, masked) in zip(self._table, self._sources):
-                    t.values, t.elem_kind, t.rows, t.masked = src.data_ptr(), kind, rows, int(masked)
-            L.check(L.lib.mdp_stats_masked_sums_multi(self._table, len(self._sources), self.env.num_envs, L.ptr(mask),
+        if not self._separate and len(self._sources) <= L.MDP_STATS_MAX_SOURCES:
+            key = mask is not None          # without a mask every family sums over all envs
+            if self._table.get(key) is None:
+                table = (L.MdpStatsSource * len(self._sources))()
+                for t, (src, rows, kind, masked) in zip(table, self._sources):
+                    t.values, t.elem_kind, t.rows, t.masked = src.data_ptr(), kind, rows, int(masked and key)
+                self._table[key] = table
+            L.check(L.lib.mdp_stats_masked_sums_multi(self._table[key], len(self._sources), self.env.num_envs, L.ptr(mask),
                                                       out.data_ptr(), stream))
             return
         off = 0

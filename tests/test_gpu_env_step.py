@@ -596,3 +596,33 @@ def test_reset_log_ring(device, single_launch):
         runs.append(at_step)
     assert runs[0] == runs[1]
     assert any(v != 0.0 for step in runs[0] for v in step.values())
+
+
+def test_episode_statistics_in_one_launch_equal_the_per_family_launches(device):
+    """EpisodeStats.fill: all families through mdp_stats_masked_sums_multi (one launch) against one
+    mdp_stats_masked_sums_typed launch per family, with the reset mask and without one; bit-identical payloads."""
+    import torch
+
+    from isaaclab_amd import _lib as L
+    from isaaclab_amd.distributed import EpisodeStats
+    from isaaclab_amd.envs.synthetic import make_velocity_env
+
+    env, rec = make_velocity_env("anymal_c_rough", num_envs=192, device=str(device), steps=3, seed=4, small_terrain=True)
+    for t in range(3):
+        rec.feed(t)
+        env.step(rec.actions[t].to(device))
+    one, per_family = EpisodeStats(env), EpisodeStats(env)
+    one._separate, per_family._separate = False, True
+    assert len(one.names) >= 10 and any(n.startswith("Episode_Termination/") for n in one.names)
+    g = torch.Generator().manual_seed(2)
+    mask = (torch.rand(192, generator=g) < 0.4).to(device)
+    for m in (mask, None):
+        a = torch.full_like(one.payload, float("nan"))
+        b = torch.full_like(one.payload, float("nan"))
+        one.fill(a, m, L.stream())
+        per_family.fill(b, m, L.stream())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(to_np(a), to_np(b))
+        counts = to_np(a).reshape(-1, 2)[:, 1]
+        expect = int(mask.sum()) if m is not None else 192
+        assert np.all(counts[:-1] == expect) and counts[-1] == 192     # Curriculum/terrain_levels: over ALL envs
