@@ -26,6 +26,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Runtime setting, before HIP loads: hipGraph launches go through the runtime's ordinary dispatch path instead of its
+# pre-captured AQL packets.  On this stack (ROCm 7.2) the packet-capture path starts a 100-node graph ~40 us later: the
+# driver's command (--steps 20: one 20-step graph per timed region) 70.05 -> 68.02 us/step, the default 256-step region
+# 67.65 -> 67.2, flat Anymal-D 42.8 -> 41.8 (same box, profiles/r03_experiments.txt exp58).  The work is the same;
+# reported as config.hip_graph_packet_capture.  An explicit setting in the environment wins.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -372,6 +379,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload_text(env, args, total),
                        "envs_per_gpu": args.envs, "hip_graph": graph is not None and replayed[0] == K,
+                       "hip_graph_packet_capture": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0",
                        "graph_replayed_steps": replayed[0], "graph_ring_steps": ring, "graph_tail_steps": tail,
                        "graph_sets": len(graphs), "frame_ring_mib": env.physics.num_frames * frame_bytes(env) / 2.0 ** 20,
                        # what the step reads of the ring between two visits of a frame (vs the 256 MiB Infinity Cache)
