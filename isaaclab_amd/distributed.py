@@ -184,13 +184,22 @@ class EpisodeStats:
             work.wait()
 
     def reduce_async(self, mask: torch.Tensor | None = None, force_collective: bool = False):
-        """Per-rank partial sums on a side stream, then one all-reduce(sum) of the packed vector.  With one rank there is
-        no collective to overlap: the sums go to the CURRENT stream, in order behind the step (a hop to the side stream
-        and back costs more than the launch -- ~25 us of cross-queue signalling on this stack)."""
-        if self.world <= 1 and not force_collective and not self._separate:
-            self.fill(self.payload, mask, L.stream(self.device))
+        """Per-rank partial sums on the CURRENT stream, in order behind the step (one launch), then one asynchronous
+        all-reduce(sum) of the packed vector: RCCL's own stream takes over from the current one through an event, the
+        current stream goes on with the next rollout and only waits for the collective when the payload is needed again
+        (the next call, or ``result()``).  Up to round 3's last day the sums ran on a side stream of their own: one more
+        cross-queue hand-over (~25 us on this stack) in front of the collective, at the end of every timed region, and
+        the sums read buffers the step's stream was already writing again.  ``MDP_STATS_SEPARATE=1`` restores that form
+        (A/B knob)."""
+        if self._separate:
+            return self._reduce_async_side_stream(mask, force_collective)
+        if self._work is not None:          # the previous collective still owns the payload (device-side wait)
+            self._work.wait()
             self._work = None
-            return
+        self.fill(self.payload, mask, L.stream(self.device))
+        self._work = allreduce_payload(self.payload, self.world, self.group, force=force_collective)
+
+    def _reduce_async_side_stream(self, mask, force_collective):
         cur = torch.cuda.current_stream(self.device)
         self._ready.record(cur)
         with torch.cuda.stream(self._stream):
