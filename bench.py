@@ -278,7 +278,7 @@ def main():
 
     def run(k_steps):
         """Exactly ``k_steps`` env steps: whole-ring graph replays, then the tail graph (eager only without graphs)."""
-        done, next_stats = 0, args.stats_every
+        done, next_stats, reduced_at = 0, args.stats_every, 0
         replayed[0] = 0
         while done < k_steps:
             left = k_steps - done
@@ -296,9 +296,11 @@ def main():
                 done += 1
             if done >= next_stats:          # end of a rollout: merge the episode statistics across ranks
                 reduce_stats()
+                reduced_at = done
                 while done >= next_stats:
                     next_stats += args.stats_every
-        reduce_stats()
+        if reduced_at < done:               # the steps behind the last whole rollout (all of them when K < --stats-every)
+            reduce_stats()
 
     def barrier():
         if world > 1:
