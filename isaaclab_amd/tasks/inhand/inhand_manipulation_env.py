@@ -291,6 +291,9 @@ class InHandManipulationEnv:
         self._finish_pending = True
         if "log" not in self.extras:
             self.extras["log"] = dict()
+        # A VIEW of the live one-element buffer, not a value like the reference's ``.mean()`` (:431): the observation
+        # launch of this same step writes the moving average into it, so it is final once ``step()`` returns and it
+        # changes again with the next step -- a logger that keeps it across steps must ``.clone()`` / ``float()`` it.
         self.extras["log"]["consecutive_successes"] = self.consecutive_successes[0]
 
     def _get_rewards(self, defer_finish: bool = False) -> torch.Tensor:
